@@ -1,0 +1,182 @@
+/*
+ * mpbp_hip.h - C ABI of libmpbp_hip.so: the MPBP message-update hot path on MI355X (gfx950).
+ *
+ * Drop-in boundary for stecrotti/MatrixProductBP.jl v0.9.0.  The reference has no FFI layer; the
+ * seam this library replaces is the body of the sweep loop
+ *
+ *     Threads.@threads for i in nodes; onebpiter!(bp, i, eltype(bp.w[i]); svd_trunc, damp); end
+ *                                                     (reference src/mpbp.jl:189-192)
+ *
+ * for factors that are `RecursiveBPFactor`s (reference src/recursive_bp_factor.jl:146-165), plus the
+ * observables the host reads afterwards (beliefs src/mpbp.jl:237, pair_beliefs src/mpbp.jl:202-235,
+ * bethe_free_energy src/mpbp.jl:298).  The host (Julia `ccall`, or the Python ctypes mirror in
+ * matrixproductbp.jl_amd/) keeps the graph, evaluates the factor interface into dense tables, owns the
+ * sweep loop / convergence callback, and calls in here once per sweep.
+ *
+ * Conventions: every call returns 0 on success or a negative MPBP_E* code and never throws or aborts
+ * across the boundary; mpbp_last_error() gives the message.  All host arrays are caller-owned,
+ * column-major ("first index fastest", as Julia stores them), float64 / int32, 0-based indices.
+ * A context is used from one host thread at a time; calls are blocking (stream-synchronised before
+ * returning) unless stated otherwise.
+ */
+#ifndef MPBP_HIP_H
+#define MPBP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpbp_ctx mpbp_ctx;
+
+enum {
+  MPBP_OK = 0,
+  MPBP_EINVAL = -1,      /* bad argument / inconsistent sizes */
+  MPBP_ENOMEM = -2,      /* device or host allocation failed */
+  MPBP_EHIP = -3,        /* a HIP runtime call failed */
+  MPBP_EUNSUPPORTED = -4,/* valid in the reference, not implemented on the device path yet */
+  MPBP_ECAPACITY = -5    /* a truncated bond exceeded the context's max_bond capacity */
+};
+
+/* SVDTrunc functors of TensorTrains.jl as used at reference src/mpbp.jl:118,186; src/mpems.jl:161. */
+enum {
+  MPBP_TRUNC_THRESH = 0,      /* TruncThresh(eps):          keep sigma_k > eps*||sigma||_2          */
+  MPBP_TRUNC_BOND = 1,        /* TruncBond(mprime):         keep min(len, mprime)                    */
+  MPBP_TRUNC_BOND_MAX = 2,    /* TruncBondMax(mprime):      as BOND, records the worst relative err  */
+  MPBP_TRUNC_BOND_THRESH = 3  /* TruncBondThresh(mprime,eps): min of both                            */
+};
+
+typedef struct {
+  int32_t kind;    /* MPBP_TRUNC_* */
+  int32_t mprime;  /* bond cap (ignored by THRESH) */
+  double eps;      /* threshold (ignored by BOND / BOND_MAX) */
+} mpbp_trunc;
+
+/*
+ * Graph + sizes.  Replaces the `g::IndexedBiDiGraph` field of `MPBP` (reference src/mpbp.jl:1-33).
+ * Neighbour lists are given explicitly so that the reference's aliased graphs (InfiniteRegularGraph,
+ * src/infinite_graph.jl:8-20: k copies of edge (1,1,1)) are expressible: for node i, position
+ * p in [nbr_ptr[i], nbr_ptr[i+1]) is its p-th neighbour, in_edge[p] the id of the message it reads,
+ * out_edge[p] the id of the message it writes (same neighbour order in both, as
+ * inedges(g,i)/outedges(g,i) guarantee, reference src/recursive_bp_factor.jl:149).
+ */
+typedef struct {
+  int32_t n_nodes;          /* nv(g) */
+  int32_t n_edges;          /* ne(g): number of stored messages */
+  int32_t T;                /* final time; T+1 cores per message */
+  int32_t q;                /* states per variable (uniform over nodes on the device path) */
+  const int32_t* nbr_ptr;   /* [n_nodes+1] */
+  const int32_t* in_edge;   /* [nbr_ptr[n_nodes]] */
+  const int32_t* out_edge;  /* [nbr_ptr[n_nodes]] */
+  int32_t max_bond;         /* capacity of every stored bond (>= the truncation cap you will use) */
+  int32_t device;           /* HIP device ordinal */
+  /* Storage slot of each message in the message slab (multi-GPU: ranks own contiguous slot ranges so
+   * that one all-gather per sweep exchanges them).  NULL => slot = edge id, n_slots = n_edges. */
+  const int32_t* slot_of_edge; /* [n_edges] or NULL */
+  int32_t n_slots;             /* 0 => n_edges */
+  /* Optional caller-owned device memory for the message slab (e.g. torch tensors that the host
+   * all-gathers with RCCL).  NULL => the context allocates.  Sizes: see mpbp_slab_layout(). */
+  void* ext_cores;   /* double[n_slots * core_slot_doubles] */
+  void* ext_bonds;   /* int32 [n_slots * (T+2)] */
+  void* stream;      /* hipStream_t to launch on; NULL => the context creates its own */
+} mpbp_desc;
+
+typedef struct {
+  int64_t core_slot_doubles;  /* doubles per message slot = (T+1)*max_bond*max_bond*q*q */
+  int64_t core_stride;        /* doubles between consecutive cores of one message */
+  int32_t bonds_per_slot;     /* T+2 */
+  int32_t n_slots;
+} mpbp_layout;
+
+typedef struct {
+  double maxerr;       /* TruncBondMax.maxerr equivalent: worst sqrt(sum dropped s^2 / sum s^2) */
+  int64_t n_compress;  /* compress! calls executed (cavity ops + message finalisations) */
+  int32_t nan_flag;    /* non-finite value met (mirrors the reference's `@error "NaN in tensor train"`) */
+  int32_t capacity_flag; /* a bond was clamped to max_bond (results then differ from the reference) */
+  int32_t jacobi_not_converged;
+  float ms_total;      /* device time of the call (HIP events on the context's stream) */
+  float ms_orth;       /* time in the dominant kernel family (orthogonalisation sweeps of `op`) */
+  int32_t n_orth_launches;
+} mpbp_stats;
+
+int mpbp_create(mpbp_ctx** out, const mpbp_desc* desc);
+void mpbp_destroy(mpbp_ctx* ctx);
+const char* mpbp_last_error(const mpbp_ctx* ctx); /* ctx may be NULL: error of the last failed create */
+int mpbp_slab_layout(const mpbp_ctx* ctx, mpbp_layout* out);
+/* Device pointers of the message slab (for the host's collective); valid until mpbp_destroy. */
+int mpbp_slab_pointers(const mpbp_ctx* ctx, void** cores, void** bonds);
+
+/*
+ * Factor of node `node` as dense tables: the RecursiveBPFactor interface
+ * (reference src/recursive_bp_factor.jl:11-27) evaluated on the host.
+ *   deg        = degree of the node (must equal nbr_ptr[node+1]-nbr_ptr[node])
+ *   nstates[l] = nstates(w, l), l = 0..deg                                            (:11)
+ *   nt         = 1 if the factor is the same at every time (w[i] = fill(w, T+1)), else T+1
+ * Tables, all with the FIRST index fastest, one block per time if nt == T+1:
+ *   prob_y  [x_next(q)][x(q)][y(nstates[deg])]                = prob_y(w, x_next, x, y, deg)         (:16)
+ *   prob_xy [k(deg)] blocks of [y(nstates[1])][x_k(q)][x_i(q)] = prob_xy(w, y, x_k, x_i, k)          (:20-22)
+ *   prob_yy blocks for every (d1,d2), d1 = 0..deg, d2 = 0..deg-d1, in that nesting order (d2 inner),
+ *           each [y(nstates[d1+d2])][y1(nstates[d1])][y2(nstates[d2])][x_i(q)]
+ *                                                              = prob_yy(w, y, y1, y2, x_i, d1, d2)  (:25-26)
+ *   prob_y0 [y(nstates[0])][x_i(q)]                            = prob_y0(w, y, x_i)                  (:27)
+ * prob_y_partial (:49-54) and prob_y_dummy (:59-61) are composed inside the library.
+ */
+int mpbp_set_factor(mpbp_ctx* ctx, int32_t node, int32_t deg, const int32_t* nstates, int32_t nt,
+                    const double* prob_y, const double* prob_xy, const double* prob_yy,
+                    const double* prob_y0);
+
+/* phi[i][t][x]: double[q][T+1][n_nodes] (x fastest)  - `bp.ϕ`, reference src/mpbp.jl:4 */
+int mpbp_set_phi(mpbp_ctx* ctx, const double* phi);
+/* psi[e][t][x_src][x_dst]: double[q][q][T+1][n_edges] (x_src fastest) - `bp.ψ`, src/mpbp.jl:5 */
+int mpbp_set_psi(mpbp_ctx* ctx, const double* psi);
+
+/*
+ * Messages `bp.μ[e]` (MPEM2, cores A[t][m,n,x_src,x_dst], reference src/mpems.jl:15-17) in packed form:
+ *   bonds[e*(T+2) + t]  = left bond of core t (t = 0..T), bonds[..+T+1] = 1
+ *   data: for each edge, cores in time order, each core column-major [b_t, b_{t+1}, q, q];
+ *   offsets[e] = index in `data` (in doubles) of edge e's first core.
+ * The messages must be normalised (z = 1), as `bp.μ` always is after set_msg!.
+ */
+int mpbp_set_messages(mpbp_ctx* ctx, const int32_t* bonds, const int64_t* offsets, const double* data);
+int mpbp_get_bonds(mpbp_ctx* ctx, int32_t* bonds /* [n_edges*(T+2)] */);
+int mpbp_get_messages(mpbp_ctx* ctx, const int64_t* offsets, double* data);
+/* reset_messages!(bp) (src/mpbp.jl:72-80): uniform bond-1 messages */
+int mpbp_reset_messages(mpbp_ctx* ctx);
+
+/*
+ * One pass of onebpiter! over `nodes` (reference src/mpbp.jl:190-192 with
+ * src/recursive_bp_factor.jl:146-165 as the body).  All listed nodes are updated from the messages as
+ * they are at entry (a Jacobi step over the list): listing an independent set of nodes is therefore
+ * identical to the reference's sequential order, and single-node lists reproduce it exactly.
+ * Writes the outgoing messages of the listed nodes, their belief marginals and f[i].
+ * If an out-edge id occurs more than once for a node (InfiniteRegularGraph) the last occurrence is
+ * the one stored, as in the reference's loop (src/recursive_bp_factor.jl:154-159).
+ */
+int mpbp_sweep(mpbp_ctx* ctx, const int32_t* nodes, int32_t n_nodes, mpbp_trunc trunc, double damp,
+               mpbp_stats* stats /* may be NULL */);
+
+/* beliefs(bp) (src/mpbp.jl:237): out[x + q*(t + (T+1)*i)] */
+int mpbp_beliefs(mpbp_ctx* ctx, double* out);
+/* pair_beliefs(bp) (src/mpbp.jl:202-235): out[x_src + q*(x_dst + q*(t + (T+1)*e))];
+ * logz_pair[e] = log z_ij of the edge (the host folds (1/d_j - 1/2) weights, src/mpbp.jl:230) */
+int mpbp_pair_beliefs(mpbp_ctx* ctx, double* out, double* logz_pair);
+/* bp.f (src/recursive_bp_factor.jl:163); bethe_free_energy(bp) = sum (src/mpbp.jl:298) */
+int mpbp_free_energy(mpbp_ctx* ctx, double* f_node /* [n_nodes] */);
+/* log z_i and sum_j log z_{i->j} of the last update of every node (diagnostics / parity tests) */
+int mpbp_logz(mpbp_ctx* ctx, double* logz_node /* [n_nodes] */, double* logz_msg /* [n_edges] */);
+
+/* Enable/disable per-kernel HIP-event timing of the dominant kernel family (costs a sync per launch). */
+int mpbp_set_profiling(mpbp_ctx* ctx, int32_t on);
+
+/* Self-test entry points used by tests/ (device building blocks against host references). */
+int mpbp_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, const double* A, const double* B,
+                       double* C);
+int mpbp_selftest_qr(int32_t device, int32_t rows, int32_t cols, const double* A, double* R);
+int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, const double* A, double* sigma,
+                      double* V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPBP_HIP_H */

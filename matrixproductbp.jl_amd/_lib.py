@@ -1,0 +1,116 @@
+"""ctypes binding of libmpbp_hip.so (C ABI: include/mpbp_hip.h).  There is NO CPU fallback: if the
+HIP library is missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmpbp_hip.so")
+SOURCES = ["mpbp_hip.hip"]
+HEADERS = ["kernels.h", "engine.h", "wg_blocks.h", os.path.join("..", "..", "include", "mpbp_hip.h")]
+
+MPBP_TRUNC_THRESH, MPBP_TRUNC_BOND, MPBP_TRUNC_BOND_MAX, MPBP_TRUNC_BOND_THRESH = 0, 1, 2, 3
+
+
+class MPBPError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmpbp_hip error {code}: {msg}")
+        self.code = code
+
+
+class Trunc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("mprime", C.c_int32), ("eps", C.c_double)]
+
+
+class Desc(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_edges", C.c_int32), ("T", C.c_int32), ("q", C.c_int32),
+                ("nbr_ptr", C.POINTER(C.c_int32)), ("in_edge", C.POINTER(C.c_int32)),
+                ("out_edge", C.POINTER(C.c_int32)), ("max_bond", C.c_int32), ("device", C.c_int32),
+                ("slot_of_edge", C.POINTER(C.c_int32)), ("n_slots", C.c_int32),
+                ("ext_cores", C.c_void_p), ("ext_bonds", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("core_slot_doubles", C.c_int64), ("core_stride", C.c_int64), ("bonds_per_slot", C.c_int32),
+                ("n_slots", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("maxerr", C.c_double), ("n_compress", C.c_int64), ("nan_flag", C.c_int32),
+                ("capacity_flag", C.c_int32), ("jacobi_not_converged", C.c_int32), ("ms_total", C.c_float),
+                ("ms_orth", C.c_float), ("n_orth_launches", C.c_int32)]
+
+
+EXPORTS = ["mpbp_create", "mpbp_destroy", "mpbp_last_error", "mpbp_slab_layout", "mpbp_slab_pointers",
+           "mpbp_set_factor", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
+           "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_pair_beliefs",
+           "mpbp_free_energy", "mpbp_logz", "mpbp_set_profiling", "mpbp_selftest_gemm", "mpbp_selftest_qr",
+           "mpbp_selftest_svd"]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value",
+           "-shared", "-fPIC", "-o", LIB_PATH] + srcs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load (never build implicitly on a box without sources newer than the binary)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MPBPError(-100, f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise MPBPError(-101, f"symbol {name} missing from {LIB_PATH}")
+    L.mpbp_last_error.restype = C.c_char_p
+    L.mpbp_last_error.argtypes = [C.c_void_p]
+    L.mpbp_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Desc)]
+    L.mpbp_destroy.argtypes = [C.c_void_p]
+    L.mpbp_destroy.restype = None
+    L.mpbp_slab_layout.argtypes = [C.c_void_p, C.POINTER(Layout)]
+    L.mpbp_slab_pointers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.mpbp_set_factor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ip, C.c_int32, dp, dp, dp, dp]
+    L.mpbp_set_phi.argtypes = [C.c_void_p, dp]
+    L.mpbp_set_psi.argtypes = [C.c_void_p, dp]
+    L.mpbp_set_messages.argtypes = [C.c_void_p, ip, lp, dp]
+    L.mpbp_get_bonds.argtypes = [C.c_void_p, ip]
+    L.mpbp_get_messages.argtypes = [C.c_void_p, lp, dp]
+    L.mpbp_reset_messages.argtypes = [C.c_void_p]
+    L.mpbp_sweep.argtypes = [C.c_void_p, ip, C.c_int32, Trunc, C.c_double, C.POINTER(Stats)]
+    L.mpbp_beliefs.argtypes = [C.c_void_p, dp]
+    L.mpbp_pair_beliefs.argtypes = [C.c_void_p, dp, dp]
+    L.mpbp_free_energy.argtypes = [C.c_void_p, dp]
+    L.mpbp_logz.argtypes = [C.c_void_p, dp, dp]
+    L.mpbp_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    L.mpbp_selftest_gemm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
+    L.mpbp_selftest_qr.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp]
+    L.mpbp_selftest_svd.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().mpbp_last_error(ctx)
+        raise MPBPError(rc, msg.decode() if msg else "?")

@@ -1,0 +1,341 @@
+// The compress engine: one workgroup turns (train1 (x) train2, coupling table) into the truncated,
+// each-matrix-normalised output train, i.e. one call of `op` in compute_prob_ys
+// (reference src/recursive_bp_factor.jl:118-131: Kronecker build :120-123 + compress! :127 +
+// normalize_eachmatrix! :128), or - with `mirror` - the `mpem2 |> compress!(is_orthogonal=:left) |>
+// normalize_eachmatrix!` chain of onebpiter! (src/recursive_bp_factor.jl:156-157, src/mpems.jl:67-94).
+//
+// Algorithm (function-equivalent to the reference's two SVD sweeps, validated against the numpy oracle to
+// 1e-14):
+//   sweep 1 (no truncation; the reference's orthogonalize_right!(TruncThresh(0.0)) is a pure gauge change):
+//       keep only the triangular factors  Lf_t  with  Lf_t Lf_t^T = X_t X_t^T,  X_t = A_t (I (x) Lf_{t+1}),
+//       by an R-only blocked Householder QR of  Y_t = X_t^T.  Y_t is built from the two factor trains
+//       through two small-matrix x streamed-tensor GEMMs - the a*b x a*b x p product core never exists.
+//   sweep 2 (truncating; the reference's orthogonalize_left!(svd_trunc)):
+//       N_t = C_{t-1} A_t (structured), M_t = N_t Lf_{t+1}; left singular vectors of M_t by QR(M_t^T)
+//       + one-sided Jacobi; SVDTrunc rule on the singular values; new core = U, carry C_t = U^T N_t.
+// Cores keep the ORIGINAL bond basis on the right, so Q is never formed or stored.
+#pragma once
+#include "wg_blocks.h"
+#include "../../include/mpbp_hip.h"
+
+struct EngProb {
+  const double* A1; const int32_t* bond1; int64_t stride1; int32_t ny1;   // cores [m,n,y1,xi]
+  const double* A2; const int32_t* bond2; int64_t stride2; int32_t ny2;   // cores [m,n,y2,xi]
+  const double* logz1; const double* logz2;                               // may be null (= 0)
+  const double* pyy; int64_t pyy_tstride;   // pyy[tp*tstride + y + ny*(y1 + ny1*(y2 + ny2*xi))]
+  int32_t ny, q, mirror, cap_out;
+  double* out; int32_t* obond; int64_t ostride; double* ologz;            // output cores [m,n,y,xi]
+};
+
+struct EngCfg {
+  int32_t L;
+  int32_t Bmax;        // max product bond  (cap1*cap2)
+  int32_t nmax;        // max rows of M_t   (cap_out*ny*q)
+  // per-slot global scratch layout (offsets in doubles)
+  int64_t off_Lf, lf_stride;   // (L+1) triangular factors, lf_stride doubles each
+  int64_t off_Z, off_Y, off_C0, off_C1, off_T1, off_Nt, off_Mt, off_JA, off_JV, off_A1c, off_A2c, off_E;
+  int64_t slot_doubles;
+  // LDS layout (offsets in doubles from the dynamic LDS base); negative => use the global copy
+  int32_t lds_gemm, lds_qr, lds_misc, lds_A1c, lds_A2c, lds_E, lds_JA, lds_JV, lds_rdim;
+  mpbp_trunc trunc;
+};
+
+struct EngStats {
+  unsigned long long maxerr_bits;
+  unsigned long long n_compress;
+  int32_t nan_flag, capacity_flag, jacobi_fail;
+};
+
+namespace eng {
+
+using namespace wg;
+
+__device__ __forceinline__ int r16(int x) { return (x + 15) & ~15; }
+
+// stage logical core t of a train into dst[m + a*(n + an*(y + ny*xi))]
+__device__ inline void stage_core(double* dst, const double* base, const int32_t* bond, int64_t stride, int L,
+                                  int t, bool mirror, int nyq) {
+  const int tp = mirror ? (L - 1 - t) : t;
+  const int pl = bond[tp], pr = bond[tp + 1];
+  const int a = mirror ? pr : pl, an = mirror ? pl : pr;
+  const double* src = base + (int64_t)tp * stride;
+  const int tot = a * an * nyq;
+  for (int idx = threadIdx.x; idx < tot; idx += WG_THREADS) {
+    int m = idx % a; int rest = idx / a; int n = rest % an; int s = rest / an;
+    int mp = mirror ? n : m, np_ = mirror ? m : n;
+    dst[idx] = src[mp + pl * (np_ + pr * s)];
+  }
+}
+
+// E_xi[(m2 + b*y) + M2*(n2 + bn*y1)] = sum_y2 pyy[y,y1,y2,xi] * A2c[m2,n2,y2,xi]
+__device__ inline void build_E(double* E, const double* A2c, const double* pyy, int b, int bn, int ny, int ny1,
+                               int ny2, int q) {
+  const int M2 = b * ny, K2 = bn * ny1;
+  const int tot = M2 * K2 * q;
+  for (int idx = threadIdx.x; idx < tot; idx += WG_THREADS) {
+    int i = idx % M2; int rest = idx / M2; int kk = rest % K2; int xi = rest / K2;
+    int m2 = i % b, y = i / b, n2 = kk % bn, y1 = kk / bn;
+    double s = 0.0;
+    for (int y2 = 0; y2 < ny2; y2++) {
+      double c = pyy[y + ny * (y1 + ny1 * (y2 + ny2 * xi))];
+      if (c != 0.0) s += c * A2c[m2 + b * (n2 + bn * (y2 + ny2 * xi))];
+    }
+    E[idx] = s;
+  }
+}
+
+__device__ inline void atomic_max_double_pos(unsigned long long* addr, double v) {
+  atomicMax(addr, (unsigned long long)__double_as_longlong(v));
+}
+
+__device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, double* lds, EngStats* stats) {
+  const int tid = threadIdx.x;
+  const int L = cfg.L;
+  const bool mirror = P.mirror != 0;
+  const int ny1 = P.ny1, ny2 = P.ny2, ny = P.ny, q = P.q;
+  double* ldsG = lds + cfg.lds_gemm;
+  double* ldsQ = lds + cfg.lds_qr;
+  double* misc = lds + cfg.lds_misc;            // [32 + 2*nmax]: reductions, sigma, order
+  double* A1c = cfg.lds_A1c >= 0 ? lds + cfg.lds_A1c : slot + cfg.off_A1c;
+  double* A2c = cfg.lds_A2c >= 0 ? lds + cfg.lds_A2c : slot + cfg.off_A2c;
+  double* E = cfg.lds_E >= 0 ? lds + cfg.lds_E : slot + cfg.off_E;
+  double* JA = cfg.lds_JA >= 0 ? lds + cfg.lds_JA : slot + cfg.off_JA;
+  double* JV = cfg.lds_JV >= 0 ? lds + cfg.lds_JV : slot + cfg.off_JV;
+  int* rdim = reinterpret_cast<int*>(lds + cfg.lds_rdim);   // [L+1]
+  double* red = misc;                        // 32 doubles
+  double* sig = misc + 32;                   // [nmax]
+  int* ord = reinterpret_cast<int*>(misc + 32 + cfg.nmax);   // [nmax]
+  double* LfS = slot + cfg.off_Lf;
+  double* Z = slot + cfg.off_Z;
+  double* Y = slot + cfg.off_Y;
+  double* T1 = slot + cfg.off_T1;
+  double* Nt = slot + cfg.off_Nt;
+  double* Mt = slot + cfg.off_Mt;
+  double* Ccur = slot + cfg.off_C0;
+  double* Cnew = slot + cfg.off_C1;
+
+  auto LB1 = [&](int t) { return mirror ? P.bond1[L - t] : P.bond1[t]; };
+  auto LB2 = [&](int t) { return mirror ? P.bond2[L - t] : P.bond2[t]; };
+  auto TP = [&](int t) { return mirror ? (L - 1 - t) : t; };
+
+  // ------------------------------------------------------------------ sweep 1: triangular factors
+  if (tid == 0) { rdim[L] = 1; LfS[(int64_t)L * cfg.lf_stride] = 1.0; }
+  __syncthreads();
+  for (int t = L - 1; t >= 1; t--) {
+    const int a = LB1(t), an = LB1(t + 1), b = LB2(t), bn = LB2(t + 1);
+    const int Bm = a * b, Bn = an * bn;
+    const int r1 = rdim[t + 1];
+    const double* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;    // [Bn x r1], ld Bn
+    stage_core(A1c, P.A1, P.bond1, P.stride1, L, t, mirror, ny1 * q);
+    stage_core(A2c, P.A2, P.bond2, P.stride2, L, t, mirror, ny2 * q);
+    __syncthreads();
+    build_E(E, A2c, P.pyy + (int64_t)TP(t) * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
+    __syncthreads();
+    // Y1: Z[(m1,y1,xi) ; (n2,k)] = sum_n1 A1[m1,n1,y1,xi] Lf1[(n1,n2),k]
+    const int M1 = a * ny1 * q;
+    gemm(M1, bn * r1, an, A1c,
+         [=](int i) { return (i % a) + a * an * (i / a); }, [=](int kk) { return a * kk; },
+         Lf1, [=](int kk) { return kk; }, [=](int j) { return (int64_t)an * j; }, true,
+         Z, [=](int i) { return i; }, [=](int j) { return (int64_t)M1 * j; }, false, ldsG);
+    // Y2 (per xi): Y[(k,y,xi) ; (m1,m2)] = sum_(n2,y1) E_xi[(m2,y),(n2,y1)] Z[(m1,y1,xi),(n2,k)]
+    const int rowsY = r1 * ny * q;
+    const int ldY = r16(rowsY);
+    const int cols16 = r16(Bm);
+    // zero padding rows / columns
+    for (int64_t idx = tid; idx < (int64_t)(ldY - rowsY) * cols16; idx += WG_THREADS) {
+      int rr = rowsY + (int)(idx % (ldY - rowsY)); int64_t c = idx / (ldY - rowsY);
+      Y[rr + (int64_t)ldY * c] = 0.0;
+    }
+    for (int64_t idx = tid; idx < (int64_t)ldY * (cols16 - Bm); idx += WG_THREADS)
+      Y[(int64_t)ldY * Bm + idx] = 0.0;
+    const int M2 = b * ny, K2 = bn * ny1;
+    for (int xi = 0; xi < q; xi++) {
+      gemm(M2, a * r1, K2, E + (int64_t)xi * M2 * K2,
+           [=](int i) { return i; }, [=](int kk) { return M2 * kk; },
+           Z + a * ny1 * xi, [=](int kk) { return (int64_t)a * (kk / bn) + (int64_t)M1 * (kk % bn); },
+           [=](int j) { return (int64_t)(j % a) + (int64_t)M1 * bn * (j / a); }, false,
+           Y + (int64_t)r1 * ny * xi,
+           [=](int i) { return (int64_t)r1 * (i / b) + (int64_t)ldY * a * (i % b); },
+           [=](int j) { return (int64_t)(j / a) + (int64_t)ldY * (j % a); }, false, ldsG);
+    }
+    qr_r(Y, ldY, rowsY, Bm, ldsQ);
+    const int kmax = min(rowsY, Bm);
+    // scale = max |R| over the upper trapezoid
+    double mx = 0.0;
+    for (int64_t idx = tid; idx < (int64_t)kmax * Bm; idx += WG_THREADS) {
+      int k = (int)(idx % kmax); int m = (int)(idx / kmax);
+      if (m >= k) mx = fmax(mx, fabs(Y[k + (int64_t)ldY * m]));
+    }
+    mx = wg_max(mx, red);
+    const double inv = (mx > 0.0 && isfinite(mx)) ? 1.0 / mx : 1.0;
+    double* Lf0 = LfS + (int64_t)t * cfg.lf_stride;                 // [Bm x kmax], ld Bm
+    for (int64_t idx = tid; idx < (int64_t)kmax * Bm; idx += WG_THREADS) {
+      int m = (int)(idx % Bm); int k = (int)(idx / Bm);
+      Lf0[m + (int64_t)Bm * k] = (m >= k) ? Y[k + (int64_t)ldY * m] * inv : 0.0;
+    }
+    if (tid == 0) rdim[t] = kmax;
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ sweep 2: truncation
+  double logc = 0.0;
+  int kc = 1;
+  if (tid == 0) Ccur[0] = 1.0;
+  if (tid == 0) { P.obond[mirror ? L : 0] = 1; P.obond[mirror ? 0 : L] = 1; }
+  __syncthreads();
+  for (int t = 0; t < L; t++) {
+    const int a = LB1(t), an = LB1(t + 1), b = LB2(t), bn = LB2(t + 1);
+    const int Bn = an * bn;
+    const int tp = TP(t);
+    stage_core(A1c, P.A1, P.bond1, P.stride1, L, t, mirror, ny1 * q);
+    stage_core(A2c, P.A2, P.bond2, P.stride2, L, t, mirror, ny2 * q);
+    __syncthreads();
+    build_E(E, A2c, P.pyy + (int64_t)tp * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
+    __syncthreads();
+    // N1: T1[(n1,y1,xi) ; (k,m2)] = sum_m1 A1[m1,n1,y1,xi] C[k,(m1,m2)]
+    const int MT1 = an * ny1 * q;
+    gemm(MT1, kc * b, a, A1c,
+         [=](int i) { return a * (i % an) + a * an * (i / an); }, [=](int kk) { return kk; },
+         Ccur, [=](int kk) { return (int64_t)kc * kk; },
+         [=](int j) { return (int64_t)(j % kc) + (int64_t)kc * a * (j / kc); }, false,
+         T1, [=](int i) { return i; }, [=](int j) { return (int64_t)MT1 * j; }, false, ldsG);
+    // N2 (per xi): Nt[(k,y,xi) ; (n1,n2)] = sum_(m2,y1) E_xi[(m2,y),(n2,y1)] T1[(n1,y1,xi),(k,m2)]
+    const int Rr = kc * ny * q;
+    const int M2 = b * ny, K2 = bn * ny1;
+    for (int xi = 0; xi < q; xi++) {
+      gemm(bn * ny, an * kc, b * ny1, E + (int64_t)xi * M2 * K2,
+           [=](int i) { return b * (i / bn) + M2 * (i % bn); },
+           [=](int kk) { return (kk % b) + M2 * bn * (kk / b); },
+           T1 + an * ny1 * xi, [=](int kk) { return (int64_t)an * (kk / b) + (int64_t)MT1 * kc * (kk % b); },
+           [=](int j) { return (int64_t)(j % an) + (int64_t)MT1 * (j / an); }, false,
+           Nt + (int64_t)kc * ny * xi,
+           [=](int i) { return (int64_t)kc * (i / bn) + (int64_t)Rr * an * (i % bn); },
+           [=](int j) { return (int64_t)(j / an) + (int64_t)Rr * (j % an); }, false, ldsG);
+    }
+    // rescale by max-abs (the reference rescales M at every step into z)
+    {
+      double mx = wg_maxabs(Nt, Rr, Rr, Bn, red);
+      if (!(mx == mx) || isinf(mx)) { if (tid == 0) stats->nan_flag = 1; }
+      if (mx > 0.0 && isfinite(mx)) {
+        const double inv = 1.0 / mx;
+        for (int64_t idx = tid; idx < (int64_t)Rr * Bn; idx += WG_THREADS) Nt[idx] *= inv;
+        logc += log(mx);
+      }
+      __syncthreads();
+    }
+    double* oc = P.out + (int64_t)tp * P.ostride;
+    if (t == L - 1) {
+      // last core: [kc, 1, s] = Nt[(k,s), 0]
+      for (int idx = tid; idx < Rr; idx += WG_THREADS) {
+        int k = idx % kc, s = idx / kc;
+        // logical (m=k, n=0): physical offset  !mirror: k + kc*(0 + 1*s);  mirror: 0 + 1*(k + kc*s)
+        oc[k + kc * s] = Nt[idx];
+      }
+      __syncthreads();
+      break;
+    }
+    const int r1 = rdim[t + 1];
+    const double* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;
+    // Mt^T [r1 x Rr] = Lf1^T Nt^T
+    const int ldM = r16(r1);
+    const int Rr16 = r16(Rr);
+    for (int64_t idx = tid; idx < (int64_t)(ldM - r1) * Rr16; idx += WG_THREADS) {
+      int rr = r1 + (int)(idx % (ldM - r1)); int64_t c = idx / (ldM - r1);
+      Mt[rr + (int64_t)ldM * c] = 0.0;
+    }
+    for (int64_t idx = tid; idx < (int64_t)ldM * (Rr16 - Rr); idx += WG_THREADS) Mt[(int64_t)ldM * Rr + idx] = 0.0;
+    gemm(r1, Rr, Bn, Lf1, [=](int i) { return (int64_t)Bn * i; }, [=](int kk) { return kk; },
+         Nt, [=](int kk) { return (int64_t)Rr * kk; }, [=](int j) { return j; }, false,
+         Mt, [=](int i) { return i; }, [=](int j) { return (int64_t)ldM * j; }, false, ldsG);
+    qr_r(Mt, ldM, r1, Rr, ldsQ);
+    const int k2 = min(r1, Rr);
+    // JA [k2 x Rr] = upper trapezoid of R2
+    for (int idx = tid; idx < k2 * Rr; idx += WG_THREADS) {
+      int r = idx % k2, c = idx / k2;
+      JA[idx] = (c >= r) ? Mt[r + (int64_t)ldM * c] : 0.0;
+    }
+    __syncthreads();
+    int sw = jacobi_rsv(JA, k2, k2, Rr, JV, Rr, red, 60);
+    if (sw < 0 && tid == 0) stats->jacobi_fail = 1;
+    // singular values = column norms; order descending
+    for (int c = tid; c < Rr; c += WG_THREADS) {
+      double s = 0.0;
+      for (int r = 0; r < k2; r++) { double v = JA[r + k2 * c]; s += v * v; }
+      sig[c] = sqrt(s);
+    }
+    __syncthreads();
+    for (int c = tid; c < Rr; c += WG_THREADS) {
+      const double sc = sig[c];
+      int rank = 0;
+      for (int j = 0; j < Rr; j++) { double sj = sig[j]; rank += (sj > sc) || (sj == sc && j < c); }
+      ord[rank] = c;
+    }
+    __syncthreads();
+    // truncation rule (TensorTrains SVDTrunc functors)
+    const int len = min(Rr, r1);
+    int kp;
+    {
+      double tot = 0.0;
+      for (int j = 0; j < len; j++) { double s = sig[ord[j]]; tot += s * s; }
+      const mpbp_trunc tr = cfg.trunc;
+      int kth = len;
+      if (tr.kind == MPBP_TRUNC_THRESH || tr.kind == MPBP_TRUNC_BOND_THRESH) {
+        const double thr = tr.eps * sqrt(tot);
+        kth = 0;
+        for (int j = 0; j < len; j++) if (sig[ord[j]] > thr) kth = j + 1;
+        if (kth < 1) kth = 1;
+      }
+      if (tr.kind == MPBP_TRUNC_THRESH) kp = kth;
+      else if (tr.kind == MPBP_TRUNC_BOND_THRESH) kp = min(kth, tr.mprime);
+      else kp = min(len, tr.mprime);
+      if (kp < 1) kp = 1;
+      if (kp > P.cap_out) { kp = P.cap_out; if (tid == 0) stats->capacity_flag = 1; }
+      if (tr.kind == MPBP_TRUNC_BOND_MAX && tid == 0 && tot > 0.0) {
+        double dropped = 0.0;
+        for (int j = kp; j < len; j++) { double s = sig[ord[j]]; dropped += s * s; }
+        atomic_max_double_pos(&stats->maxerr_bits, sqrt(dropped / tot));
+      }
+    }
+    // new core t: logical [kc, kp, s] = V[(k + kc*s), ord[k']]
+    for (int idx = tid; idx < Rr * kp; idx += WG_THREADS) {
+      int row = idx % Rr, k2i = idx / Rr;
+      int k = row % kc, s = row / kc;
+      double v = JV[row + Rr * ord[k2i]];
+      // physical layout: !mirror [kc, kp, s];  mirror [kp, kc, s]
+      int64_t off = mirror ? ((int64_t)k2i + (int64_t)kp * (k + (int64_t)kc * s))
+                           : ((int64_t)k + (int64_t)kc * (k2i + (int64_t)kp * s));
+      oc[off] = v;
+    }
+    if (tid == 0) P.obond[mirror ? (L - (t + 1)) : (t + 1)] = kp;
+    // carry C' [kp x Bn] = U^T Nt
+    gemm(kp, Bn, Rr, JV, [=](int i) { return (int64_t)Rr * ord[i]; }, [=](int kk) { return kk; },
+         Nt, [=](int kk) { return kk; }, [=](int j) { return (int64_t)Rr * j; }, true,
+         Cnew, [=](int i) { return i; }, [=](int j) { return (int64_t)kp * j; }, false, ldsG);
+    double* tmp = Ccur; Ccur = Cnew; Cnew = tmp;
+    kc = kp;
+  }
+
+  // ------------------------------------------------------------------ normalize_eachmatrix! + z
+  double logz = (P.logz1 ? *P.logz1 : 0.0) + (P.logz2 ? *P.logz2 : 0.0) - logc;
+  __syncthreads();
+  for (int tp = 0; tp < L; tp++) {
+    const int n = P.obond[tp] * P.obond[tp + 1] * ny * q;
+    double* oc = P.out + (int64_t)tp * P.ostride;
+    double mx = 0.0;
+    for (int idx = tid; idx < n; idx += WG_THREADS) mx = fmax(mx, fabs(oc[idx]));
+    mx = wg_max(mx, red);
+    if (mx > 0.0 && isfinite(mx)) {
+      const double inv = 1.0 / mx;
+      for (int idx = tid; idx < n; idx += WG_THREADS) oc[idx] *= inv;
+      logz -= log(mx);
+    }
+  }
+  if (tid == 0) {
+    *P.ologz = logz;
+    atomicAdd(&stats->n_compress, 1ULL);
+    if (!(logz == logz)) stats->nan_flag = 1;
+  }
+  __syncthreads();
+}
+
+}  // namespace eng

@@ -1,0 +1,386 @@
+// Device kernels of libmpbp_hip: the compress engine launcher and the HBM-bound scan kernels
+// (Pxy application, MPEM3 -> explicit MPEM2 embedding, environment scans for normalize!/marginals,
+// pair beliefs).  gfx950 only.
+#pragma once
+#include "engine.h"
+
+// ------------------------------------------------------------------------------------------------
+// engine launcher: persistent workgroups pull problems (sorted by decreasing cost) from a counter
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG_THREADS)
+eng_kernel(const EngProb* probs, int nprob, int* counter, EngCfg cfg, double* scratch, EngStats* stats) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ int s_p;
+  double* slot = scratch + (int64_t)blockIdx.x * cfg.slot_doubles;
+  for (;;) {
+    if (threadIdx.x == 0) s_p = atomicAdd(counter, 1);
+    __syncthreads();
+    const int p = s_p;
+    __syncthreads();
+    if (p >= nprob) break;
+    eng::run_problem(probs[p], cfg, slot, lds, stats);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: B_k[t][m,n,y,xi] = sum_xk Pxy[t][y,xk,xi] mu_{k->i}[t][m,n,xk,xi]
+//   (reference src/recursive_bp_factor.jl:108-115; psi_ik is folded into the table by the host)
+// ------------------------------------------------------------------------------------------------
+struct PrepProb {
+  const double* msg; const int32_t* mbond; int64_t mstride;
+  const double* tab; int64_t tab_tstride;    // tab[t*tstride + y + ny1*(xk + q*xi)]
+  double* out; int32_t* obond; int64_t ostride; double* ologz;
+  int32_t ny1, q;
+};
+
+__global__ void prep_kernel(const PrepProb* probs, int L) {
+  const PrepProb P = probs[blockIdx.y];
+  const int t = blockIdx.x;
+  const int bl = P.mbond[t], br = P.mbond[t + 1];
+  if (threadIdx.x == 0) {
+    P.obond[t] = bl;
+    if (t == L - 1) { P.obond[L] = br; *P.ologz = 0.0; }
+  }
+  const double* A = P.msg + (int64_t)t * P.mstride;
+  const double* tab = P.tab + (int64_t)t * P.tab_tstride;
+  double* O = P.out + (int64_t)t * P.ostride;
+  const int bb = bl * br, q = P.q, ny1 = P.ny1;
+  const int tot = bb * ny1 * q;
+  for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+    int mn = idx % bb; int rest = idx / bb; int y = rest % ny1; int xi = rest / ny1;
+    double s = 0.0;
+    for (int xk = 0; xk < q; xk++) s += tab[y + ny1 * (xk + q * xi)] * A[mn + bb * (xk + q * xi)];
+    O[idx] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ctilde: apply the transition table and embed the MPEM3 as an explicit MPEM2 of doubled bond
+//   B[t][m,n,xi,xj,x'] = sum_y W[t][x',xi,xj,y] A[t][m,n,y,xi]        (src/recursive_bp_factor.jl:79-84)
+//   Ct[t][(m,a),(n,x'),(xi,xj)] = delta(a,xi) B[t][m,n,xi,xj,x']       (exact restatement of the index
+//   move that mpem2's SVD sweep performs, src/mpems.jl:67-94; first core has no `a`, last no `x'`)
+// ------------------------------------------------------------------------------------------------
+struct CtProb {
+  const double* in; const int32_t* ibond; int64_t istride; const double* ilogz; int32_t ny;
+  const double* W;      // W[t*(q*q*qj*ny) + x' + q*(xi + q*(xj + qj*y))]
+  int32_t q, qj;
+  double* out; int32_t* obond; int64_t ostride; double* ologz;
+};
+
+__global__ void ctilde_kernel(const CtProb* probs, int L) {
+  const CtProb P = probs[blockIdx.y];
+  const int t = blockIdx.x;
+  const int q = P.q, qj = P.qj, ny = P.ny;
+  const int bl = P.ibond[t], br = P.ibond[t + 1];
+  const int cl = (t == 0) ? 1 : bl * q, cr = (t == L - 1) ? 1 : br * q;
+  if (threadIdx.x == 0) {
+    P.obond[t] = cl;
+    if (t == L - 1) { P.obond[L] = 1; *P.ologz = P.ilogz ? *P.ilogz : 0.0; }
+  }
+  const double* A = P.in + (int64_t)t * P.istride;
+  const double* W = P.W + (int64_t)t * q * q * qj * ny;
+  double* O = P.out + (int64_t)t * P.ostride;
+  const int na = (t == 0) ? 1 : q, nxp = (t == L - 1) ? 1 : q;
+  const int tot = cl * cr * q * qj;
+  for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+    int row = idx % cl; int rest = idx / cl; int col = rest % cr; rest /= cr; int xi = rest % q; int xj = rest / q;
+    int m = row % bl, aa = row / bl;            // (m,a): m fastest (t==0: bl==1 -> m=0, aa=0)
+    int n = col % br, xp = col / br;            // (n,x')
+    double v = 0.0;
+    if (na == 1 || aa == xi) {
+      for (int y = 0; y < ny; y++)
+        v += W[xp + q * (xi + q * (xj + qj * y))] * A[m + bl * (n + br * (y + ny * xi))];
+    }
+    (void)nxp;
+    O[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// env: environment scans of an explicit train: log sum_x prod_t A_t(x_t) (normalize!, normalization),
+// per-site marginals, and the rescaled copy that becomes the stored message.
+// ------------------------------------------------------------------------------------------------
+struct EnvProb {
+  const double* in; const int32_t* ibond; int64_t istride; const double* ilogz; int32_t p;
+  double* dst; int32_t* dbond; int64_t dstride;   // normalised copy (sum = 1, z = 1) or null
+  double* marg;                                    // [p x L] marginals or null
+  double* logz_out;                                // log normalisation (incl. z) or null
+  double* rvec;                                    // scratch [L+1][bmax]
+  int32_t bmax;
+};
+
+__global__ void env_kernel(const EnvProb* probs, int L) {
+  const EnvProb P = probs[blockIdx.x];
+  __shared__ double sh[256 + 1024 + 64];
+  __shared__ double s_scale;
+  double* lv = sh;          // [<=256] left vector
+  double* tmp = sh + 256;   // [<=1024]
+  double* red = sh + 1280;  // [64]
+  const int tid = threadIdx.x;
+  const int p = P.p;
+  // backward pass
+  if (tid == 0) P.rvec[(int64_t)L * P.bmax] = 1.0;
+  __syncthreads();
+  double logP = 0.0;
+  for (int t = L - 1; t >= 0; t--) {
+    const int bl = P.ibond[t], br = P.ibond[t + 1];
+    const double* A = P.in + (int64_t)t * P.istride;
+    const double* rn = P.rvec + (int64_t)(t + 1) * P.bmax;
+    double* rt = P.rvec + (int64_t)t * P.bmax;
+    double mx = 0.0;
+    for (int m = tid; m < bl; m += blockDim.x) {
+      double s = 0.0;
+      for (int n = 0; n < br; n++) {
+        double a = 0.0;
+        for (int x = 0; x < p; x++) a += A[m + bl * (n + br * x)];
+        s += a * rn[n];
+      }
+      tmp[m] = s;
+      mx = fmax(mx, fabs(s));
+    }
+    // block max
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      double m2 = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); w++) m2 = fmax(m2, red[w]);
+      s_scale = m2;
+    }
+    __syncthreads();
+    const double sc = s_scale;
+    const double inv = (sc > 0.0 && isfinite(sc)) ? 1.0 / sc : 1.0;
+    if (sc > 0.0 && isfinite(sc)) logP += log(sc);
+    for (int m = tid; m < bl; m += blockDim.x) rt[m] = tmp[m] * inv;
+    __syncthreads();
+  }
+  {
+    double r0 = P.rvec[0];
+    logP += log(fabs(r0));     // r0 is +-1 after rescaling (or 0 -> -inf)
+  }
+  const double logz_in = P.ilogz ? *P.ilogz : 0.0;
+  if (tid == 0 && P.logz_out) *P.logz_out = logP - logz_in;
+  // normalised copy
+  if (P.dst) {
+    const double f = exp(-logP / L);
+    for (int t = 0; t < L; t++) {
+      const int n = P.ibond[t] * P.ibond[t + 1] * p;
+      const double* A = P.in + (int64_t)t * P.istride;
+      double* D = P.dst + (int64_t)t * P.dstride;
+      for (int idx = tid; idx < n; idx += blockDim.x) D[idx] = A[idx] * f;
+    }
+    for (int t = tid; t <= L; t += blockDim.x) P.dbond[t] = P.ibond[t];
+  }
+  // forward pass: marginals
+  if (P.marg) {
+    if (tid == 0) lv[0] = 1.0;
+    __syncthreads();
+    for (int t = 0; t < L; t++) {
+      const int bl = P.ibond[t], br = P.ibond[t + 1];
+      const double* A = P.in + (int64_t)t * P.istride;
+      const double* rn = P.rvec + (int64_t)(t + 1) * P.bmax;
+      // val_x = sum_{m,n} l[m] A[m,n,x] r[n]   (threads over (n,x))
+      for (int idx = tid; idx < br * p; idx += blockDim.x) {
+        int n = idx % br, x = idx / br;
+        double s = 0.0;
+        for (int m = 0; m < bl; m++) s += lv[m] * A[m + bl * (n + br * x)];
+        tmp[idx] = s;      // [n + br*x] = (l A_x)[n]
+      }
+      __syncthreads();
+      if (tid < p) {
+        double v = 0.0;
+        for (int n = 0; n < br; n++) v += tmp[n + br * tid] * rn[n];
+        red[tid] = v;
+      }
+      __syncthreads();
+      if (tid < p) {
+        double tot = 0.0;
+        for (int x = 0; x < p; x++) tot += red[x];
+        P.marg[tid + p * t] = red[tid] / tot;
+      }
+      // l <- l * sum_x A_x, rescaled
+      double mx = 0.0;
+      double mine = 0.0;
+      if (tid < br) {
+        for (int x = 0; x < p; x++) mine += tmp[tid + br * x];
+        mx = fabs(mine);
+      }
+      for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+      __syncthreads();
+      if ((tid & 63) == 0) red[16 + (tid >> 6)] = mx;
+      __syncthreads();
+      double m2 = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); w++) m2 = fmax(m2, red[16 + w]);
+      const double inv = (m2 > 0.0 && isfinite(m2)) ? 1.0 / m2 : 1.0;
+      if (tid < br) lv[tid] = mine * inv;
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair beliefs: environments of the Kronecker train mu_ij (x) mu_ji * psi without forming it
+//   (reference src/bp_core.jl:95-109, src/mpbp.jl:218-235).  One workgroup per directed edge.
+//   l[a,b] (x) -> l'[a',b'] = sum_{xi,xj} psi[xi,xj] (Aij_{xi,xj}^T l Aji_{xj,xi})
+// ------------------------------------------------------------------------------------------------
+struct PairProb {
+  const double* aij; const int32_t* bij; const double* aji; const int32_t* bji; int64_t stride;
+  const double* psi;       // psi[t*q*q + xi + q*xj]
+  double* out;             // [q x q x L]
+  double* logz;            // log z_ij
+  double* scratch;         // [(L+1) * cap*cap] right environments + 2*cap*cap work
+  int32_t q, cap;
+};
+
+__device__ inline void pair_apply_left(const double* l, const double* Aij, const double* Aji, int a, int a2, int b,
+                                       int b2, int xi, int xj, int q, double* tmpm, double* outm, double w,
+                                       bool accumulate) {
+  // tmpm[a', bq] = sum_a Aij[a,a',xi,xj] l[a,bq] ; outm[a',b'] (+)= w * sum_bq tmpm[a',bq] Aji[bq,b',xj,xi]
+  const double* X = Aij + (int64_t)a * a2 * (xi + q * xj);
+  const double* Yj = Aji + (int64_t)b * b2 * (xj + q * xi);
+  for (int idx = threadIdx.x; idx < a2 * b; idx += blockDim.x) {
+    int ap = idx % a2, bq = idx / a2;
+    double s = 0.0;
+    for (int aa = 0; aa < a; aa++) s += X[aa + a * ap] * l[aa + a * bq];
+    tmpm[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < a2 * b2; idx += blockDim.x) {
+    int ap = idx % a2, bp = idx / a2;
+    double s = 0.0;
+    for (int bq = 0; bq < b; bq++) s += tmpm[ap + a2 * bq] * Yj[bq + b * bp];
+    outm[idx] = (accumulate ? outm[idx] : 0.0) + w * s;
+  }
+  __syncthreads();
+}
+
+__device__ inline void pair_apply_right(const double* r, const double* Aij, const double* Aji, int a, int a2, int b,
+                                        int b2, int xi, int xj, int q, double* tmpm, double* outm, double w,
+                                        bool accumulate) {
+  // tmpm[a, b'] = sum_a' Aij[a,a',xi,xj] r[a',b'] ; outm[a,b] (+)= w * sum_b' tmpm[a,b'] Aji[b,b',xj,xi]
+  const double* X = Aij + (int64_t)a * a2 * (xi + q * xj);
+  const double* Yj = Aji + (int64_t)b * b2 * (xj + q * xi);
+  for (int idx = threadIdx.x; idx < a * b2; idx += blockDim.x) {
+    int aa = idx % a, bp = idx / a;
+    double s = 0.0;
+    for (int ap = 0; ap < a2; ap++) s += X[aa + a * ap] * r[ap + a2 * bp];
+    tmpm[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < a * b; idx += blockDim.x) {
+    int aa = idx % a, bq = idx / a;
+    double s = 0.0;
+    for (int bp = 0; bp < b2; bp++) s += tmpm[aa + a * bp] * Yj[bq + b * bp];
+    outm[idx] = (accumulate ? outm[idx] : 0.0) + w * s;
+  }
+  __syncthreads();
+}
+
+__device__ inline double block_maxabs_scale(double* v, int n, double* red) {
+  double mx = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmax(mx, fabs(v[i]));
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  double m2 = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); w++) m2 = fmax(m2, red[w]);
+  if (m2 > 0.0 && isfinite(m2)) {
+    const double inv = 1.0 / m2;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v[i] *= inv;
+  }
+  __syncthreads();
+  return m2;
+}
+
+__global__ void pair_kernel(const PairProb* probs, int L) {
+  const PairProb P = probs[blockIdx.x];
+  __shared__ double red[16];
+  const int q = P.q, cc = P.cap * P.cap;
+  double* R = P.scratch;                         // [(L+1)][cc]
+  double* work = P.scratch + (int64_t)(L + 1) * cc;   // tmp [cc], lcur [cc], lnew [cc]
+  double* tmpm = work, *lcur = work + cc, *lnew = work + 2 * cc;
+  // right environments
+  if (threadIdx.x == 0) R[(int64_t)L * cc] = 1.0;
+  __syncthreads();
+  for (int t = L - 1; t >= 0; t--) {
+    const int a = P.bij[t], a2 = P.bij[t + 1], b = P.bji[t], b2 = P.bji[t + 1];
+    const double* Aij = P.aij + (int64_t)t * P.stride;
+    const double* Aji = P.aji + (int64_t)t * P.stride;
+    double* rt = R + (int64_t)t * cc;
+    const double* rn = R + (int64_t)(t + 1) * cc;
+    bool first = true;
+    for (int xi = 0; xi < q; xi++)
+      for (int xj = 0; xj < q; xj++) {
+        pair_apply_right(rn, Aij, Aji, a, a2, b, b2, xi, xj, q, tmpm, rt, P.psi[(int64_t)t * q * q + xi + q * xj], !first);
+        first = false;
+      }
+    block_maxabs_scale(rt, a * b, red);
+  }
+  // forward: marginals and log z
+  if (threadIdx.x == 0) lcur[0] = 1.0;
+  __syncthreads();
+  double logz = 0.0;
+  for (int t = 0; t < L; t++) {
+    const int a = P.bij[t], a2 = P.bij[t + 1], b = P.bji[t], b2 = P.bji[t + 1];
+    const double* Aij = P.aij + (int64_t)t * P.stride;
+    const double* Aji = P.aji + (int64_t)t * P.stride;
+    const double* rn = R + (int64_t)(t + 1) * cc;
+    double vals[16];
+    double tot = 0.0;
+    for (int xi = 0; xi < q; xi++)
+      for (int xj = 0; xj < q; xj++) {
+        // lx = l applied with (xi,xj) only, then <lx, r>
+        pair_apply_left(lcur, Aij, Aji, a, a2, b, b2, xi, xj, q, tmpm, lnew, P.psi[(int64_t)t * q * q + xi + q * xj], false);
+        double s = 0.0;
+        for (int i = threadIdx.x; i < a2 * b2; i += blockDim.x) s += lnew[i] * rn[i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        double v = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) v += red[w];
+        __syncthreads();
+        if (xi + q * xj < 16) vals[xi + q * xj] = v;
+        tot += v;
+      }
+    if (threadIdx.x == 0)
+      for (int s = 0; s < q * q && s < 16; s++) P.out[s + q * q * t] = vals[s] / tot;
+    // advance l with the summed core
+    bool first = true;
+    for (int xi = 0; xi < q; xi++)
+      for (int xj = 0; xj < q; xj++) {
+        pair_apply_left(lcur, Aij, Aji, a, a2, b, b2, xi, xj, q, tmpm, lnew, P.psi[(int64_t)t * q * q + xi + q * xj], !first);
+        first = false;
+      }
+    double m2 = block_maxabs_scale(lnew, a2 * b2, red);
+    if (m2 > 0.0 && isfinite(m2)) logz += log(m2);
+    double* sw = lcur; lcur = lnew; lnew = sw;
+  }
+  if (threadIdx.x == 0) *P.logz = logz + log(fabs(lcur[0]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// self-test kernels (building blocks against host references; used by tests/)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG_THREADS) st_gemm_kernel(int M, int N, int K, const double* A, const double* B, double* C) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  wg::gemm(M, N, K, A, [=](int i) { return i; }, [=](int k) { return (int64_t)M * k; },
+           B, [=](int k) { return k; }, [=](int j) { return (int64_t)K * j; }, true,
+           C, [=](int i) { return i; }, [=](int j) { return (int64_t)M * j; }, false, lds);
+}
+__global__ void __launch_bounds__(WG_THREADS) st_qr_kernel(double* Y, int ld, int rows, int cols) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  wg::qr_r(Y, ld, rows, cols, lds);
+}
+__global__ void __launch_bounds__(WG_THREADS) st_svd_kernel(double* A, int m, int n, double* V, double* sigma, int* sweeps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  int sw = wg::jacobi_rsv(A, m, m, n, V, n, lds, 60);
+  for (int c = threadIdx.x; c < n; c += WG_THREADS) {
+    double s = 0.0;
+    for (int r = 0; r < m; r++) s += A[r + (int64_t)m * c] * A[r + (int64_t)m * c];
+    sigma[c] = sqrt(s);
+  }
+  if (threadIdx.x == 0) *sweeps = sw;
+}

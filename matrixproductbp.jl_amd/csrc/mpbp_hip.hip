@@ -1,0 +1,899 @@
+// libmpbp_hip.so - host side of the C ABI declared in include/mpbp_hip.h.
+// Host responsibilities: compose the per-node tables from the factor primitives (prob_y_partial,
+// reference src/recursive_bp_factor.jl:49-54), unroll CavityTools.cavity into a levelled DAG of `op`s
+// (src/recursive_bp_factor.jl:140), lay trains out in HBM and launch the kernels of kernels.h.
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+static thread_local std::string g_create_error;
+
+#define HIPCHK(ctx, call)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      return (ctx)->fail(MPBP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                             \
+  } while (0)
+
+namespace {
+
+struct DevTrain {       // a tensor train resident in HBM
+  double* cores = nullptr; int32_t* bonds = nullptr; double* logz = nullptr;
+  int64_t stride = 0;   // doubles between cores
+  int cap = 0, ny = 0, d = 0, level = 0;
+};
+
+struct NodeFactor {
+  bool set = false; int deg = 0, nt = 1;
+  std::vector<int> ny;
+  std::vector<double> prob_y, prob_xy, prob_yy, prob_y0;
+  std::vector<int64_t> yy_off;   // offset of block (d1,d2) inside one time block of prob_yy
+  int64_t yy_tblock = 0;
+};
+
+// bump allocator over one device arena, regrown on demand between sweeps
+struct Arena {
+  char* base = nullptr; size_t cap = 0, used = 0, want = 0;
+  void reset() { used = 0; want = 0; }
+  void* take(size_t bytes) {
+    size_t a = (bytes + 255) & ~size_t(255);
+    want += a;
+    if (used + a > cap) { return nullptr; }
+    void* p = base + used; used += a; return p;
+  }
+};
+
+}  // namespace
+
+struct mpbp_ctx {
+  int N = 0, E = 0, T = 0, L = 0, q = 0, cap = 0, device = 0, nslots = 0;
+  std::vector<int> nbr_ptr, in_edge, out_edge, slot_of_edge;
+  std::vector<NodeFactor> fac;
+  std::vector<double> phi, psi;           // host copies (ABI layouts)
+  bool own_cores = false, own_bonds = false, own_stream = false;
+  double* d_cores = nullptr; int32_t* d_bonds = nullptr;
+  int64_t core_stride = 0, slot_doubles = 0;
+  hipStream_t stream = nullptr;
+  // persistent outputs
+  double* d_beliefs = nullptr;    // [q][L][N]
+  double* d_logz_node = nullptr;  // [N]
+  double* d_logz_pos = nullptr;   // [nnz]  log z_{i->j} per neighbour position
+  std::vector<double> h_logz_node, h_logz_pos, h_f;
+  EngStats* d_stats = nullptr; int* d_counter = nullptr;
+  double* d_one = nullptr; int32_t* d_ones = nullptr; double* d_ident = nullptr; int ident_n = 0;
+  // tables
+  bool tables_dirty = true;
+  double* d_tab = nullptr; size_t tab_doubles = 0;
+  std::vector<int64_t> pxy_off;    // per neighbour position
+  std::vector<int64_t> pxy_tstride;
+  std::vector<int64_t> wmsg_off;   // per neighbour position
+  std::vector<int64_t> wbel_off;   // per node
+  std::vector<int64_t> init_off;   // per node: [ny0][q]
+  std::vector<int64_t> pyy_base;   // per node: offset of prob_yy blob
+  Arena arena, scratch;
+  int num_cu = 256;
+  bool profiling = false;
+  std::string err;
+  mpbp_stats last{};
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    err = buf; return code;
+  }
+  int nnz() const { return nbr_ptr[N]; }
+  double* slot_cores(int e) const { return d_cores + (int64_t)slot_of_edge[e] * slot_doubles; }
+  int32_t* slot_bonds(int e) const { return d_bonds + (int64_t)slot_of_edge[e] * (L + 1); }
+};
+
+// ================================================================================================
+// creation / destruction
+// ================================================================================================
+extern "C" const char* mpbp_last_error(const mpbp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mpbp_create(mpbp_ctx** out, const mpbp_desc* d) {
+  if (!out || !d) { g_create_error = "null argument"; return MPBP_EINVAL; }
+  *out = nullptr;
+  if (d->n_nodes <= 0 || d->n_edges <= 0 || d->T < 1 || d->q < 1 || d->q > 4 || d->max_bond < 1 || !d->nbr_ptr ||
+      !d->in_edge || !d->out_edge) { g_create_error = "invalid descriptor (need n_nodes,n_edges>0, T>=1, 1<=q<=4, max_bond>=1)"; return MPBP_EINVAL; }
+  mpbp_ctx* c = new mpbp_ctx();
+  c->N = d->n_nodes; c->E = d->n_edges; c->T = d->T; c->L = d->T + 1; c->q = d->q; c->cap = d->max_bond; c->device = d->device;
+  c->nbr_ptr.assign(d->nbr_ptr, d->nbr_ptr + c->N + 1);
+  const int nnz = c->nbr_ptr[c->N];
+  c->in_edge.assign(d->in_edge, d->in_edge + nnz);
+  c->out_edge.assign(d->out_edge, d->out_edge + nnz);
+  for (int p = 0; p < nnz; p++)
+    if (c->in_edge[p] < 0 || c->in_edge[p] >= c->E || c->out_edge[p] < 0 || c->out_edge[p] >= c->E) {
+      g_create_error = "edge id out of range"; delete c; return MPBP_EINVAL;
+    }
+  c->nslots = d->n_slots > 0 ? d->n_slots : c->E;
+  c->slot_of_edge.resize(c->E);
+  for (int e = 0; e < c->E; e++) {
+    c->slot_of_edge[e] = d->slot_of_edge ? d->slot_of_edge[e] : e;
+    if (c->slot_of_edge[e] < 0 || c->slot_of_edge[e] >= c->nslots) { g_create_error = "slot_of_edge out of range"; delete c; return MPBP_EINVAL; }
+  }
+  c->fac.resize(c->N);
+  c->core_stride = (int64_t)c->cap * c->cap * c->q * c->q;
+  c->slot_doubles = c->core_stride * c->L;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); delete c; return MPBP_EHIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  auto bail = [&](const char* what, hipError_t er) { g_create_error = std::string(what) + ": " + hipGetErrorString(er); mpbp_destroy(c); return er == hipErrorOutOfMemory ? MPBP_ENOMEM : MPBP_EHIP; };
+  if (d->stream) c->stream = (hipStream_t)d->stream;
+  else { if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e); c->own_stream = true; }
+  if (d->ext_cores) c->d_cores = (double*)d->ext_cores;
+  else { if ((e = hipMalloc(&c->d_cores, sizeof(double) * c->slot_doubles * c->nslots)) != hipSuccess) return bail("hipMalloc(message slab)", e); c->own_cores = true; }
+  if (d->ext_bonds) c->d_bonds = (int32_t*)d->ext_bonds;
+  else { if ((e = hipMalloc(&c->d_bonds, sizeof(int32_t) * (c->L + 1) * c->nslots)) != hipSuccess) return bail("hipMalloc(bonds)", e); c->own_bonds = true; }
+  if ((e = hipMalloc(&c->d_beliefs, sizeof(double) * c->q * c->L * c->N)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_logz_node, sizeof(double) * c->N)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_logz_pos, sizeof(double) * nnz)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_stats, sizeof(EngStats))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_counter, sizeof(int) * 64)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_one, sizeof(double) * 4)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_ones, sizeof(int32_t) * (c->L + 2))) != hipSuccess) return bail("hipMalloc", e);
+  c->ident_n = c->q * c->q;
+  if ((e = hipMalloc(&c->d_ident, sizeof(double) * c->ident_n * c->ident_n)) != hipSuccess) return bail("hipMalloc", e);
+  {
+    double one[4] = {1.0, 0.0, 0.0, 0.0};
+    std::vector<int32_t> ones(c->L + 2, 1);
+    std::vector<double> id((size_t)c->ident_n * c->ident_n, 0.0);
+    for (int i = 0; i < c->ident_n; i++) id[i + (size_t)c->ident_n * i] = 1.0;
+    hipMemcpy(c->d_one, one, sizeof one, hipMemcpyHostToDevice);
+    hipMemcpy(c->d_ones, ones.data(), sizeof(int32_t) * ones.size(), hipMemcpyHostToDevice);
+    hipMemcpy(c->d_ident, id.data(), sizeof(double) * id.size(), hipMemcpyHostToDevice);
+    hipMemset(c->d_beliefs, 0, sizeof(double) * c->q * c->L * c->N);
+    hipMemset(c->d_logz_node, 0, sizeof(double) * c->N);
+    hipMemset(c->d_logz_pos, 0, sizeof(double) * nnz);
+  }
+  c->h_logz_node.assign(c->N, 0.0); c->h_logz_pos.assign(nnz, 0.0); c->h_f.assign(c->N, 0.0);
+  c->phi.assign((size_t)c->q * c->L * c->N, 1.0);
+  c->psi.assign((size_t)c->q * c->q * c->L * c->E, 1.0);
+  *out = c;
+  int rc = mpbp_reset_messages(c);
+  if (rc != MPBP_OK) { g_create_error = c->err; mpbp_destroy(c); *out = nullptr; return rc; }
+  return MPBP_OK;
+}
+
+extern "C" void mpbp_destroy(mpbp_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->own_cores && c->d_cores) hipFree(c->d_cores);
+  if (c->own_bonds && c->d_bonds) hipFree(c->d_bonds);
+  for (void* p : {(void*)c->d_beliefs, (void*)c->d_logz_node, (void*)c->d_logz_pos, (void*)c->d_stats, (void*)c->d_counter,
+                  (void*)c->d_one, (void*)c->d_ones, (void*)c->d_ident, (void*)c->d_tab, (void*)c->arena.base, (void*)c->scratch.base})
+    if (p) hipFree(p);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int mpbp_slab_layout(const mpbp_ctx* c, mpbp_layout* out) {
+  if (!c || !out) return MPBP_EINVAL;
+  out->core_slot_doubles = c->slot_doubles; out->core_stride = c->core_stride; out->bonds_per_slot = c->L + 1; out->n_slots = c->nslots;
+  return MPBP_OK;
+}
+extern "C" int mpbp_slab_pointers(const mpbp_ctx* c, void** cores, void** bonds) {
+  if (!c) return MPBP_EINVAL;
+  if (cores) *cores = c->d_cores;
+  if (bonds) *bonds = c->d_bonds;
+  return MPBP_OK;
+}
+extern "C" int mpbp_set_profiling(mpbp_ctx* c, int32_t on) { if (!c) return MPBP_EINVAL; c->profiling = on != 0; return MPBP_OK; }
+
+// ================================================================================================
+// inputs
+// ================================================================================================
+extern "C" int mpbp_set_factor(mpbp_ctx* c, int32_t node, int32_t deg, const int32_t* nstates, int32_t nt,
+                               const double* prob_y, const double* prob_xy, const double* prob_yy, const double* prob_y0) {
+  if (!c) return MPBP_EINVAL;
+  if (node < 0 || node >= c->N) return c->fail(MPBP_EINVAL, "node %d out of range", node);
+  if (deg != c->nbr_ptr[node + 1] - c->nbr_ptr[node]) return c->fail(MPBP_EINVAL, "node %d: degree %d does not match the graph (%d)", node, deg, c->nbr_ptr[node + 1] - c->nbr_ptr[node]);
+  if (nt != 1 && nt != c->L) return c->fail(MPBP_EINVAL, "nt must be 1 or T+1");
+  if (!nstates || !prob_y || !prob_yy || !prob_y0 || (deg > 0 && !prob_xy)) return c->fail(MPBP_EINVAL, "null table");
+  NodeFactor& f = c->fac[node];
+  f.set = true; f.deg = deg; f.nt = nt; f.ny.assign(nstates, nstates + deg + 1);
+  for (int l = 0; l <= deg; l++) if (f.ny[l] < 1) return c->fail(MPBP_EINVAL, "nstates must be >= 1");
+  const int q = c->q;
+  const int64_t ny_sz = (int64_t)q * q * f.ny[deg];
+  const int64_t xy_sz = deg > 0 ? (int64_t)deg * f.ny[1] * q * q : 0;
+  f.yy_off.assign((size_t)(deg + 1) * (deg + 1), -1);
+  int64_t off = 0;
+  for (int d1 = 0; d1 <= deg; d1++)
+    for (int d2 = 0; d2 <= deg - d1; d2++) { f.yy_off[d1 * (deg + 1) + d2] = off; off += (int64_t)f.ny[d1 + d2] * f.ny[d1] * f.ny[d2] * q; }
+  f.yy_tblock = off;
+  f.prob_y.assign(prob_y, prob_y + ny_sz * nt);
+  f.prob_xy.assign(prob_xy, prob_xy + xy_sz * nt);
+  f.prob_yy.assign(prob_yy, prob_yy + off * nt);
+  f.prob_y0.assign(prob_y0, prob_y0 + (int64_t)f.ny[0] * q * nt);
+  c->tables_dirty = true;
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_set_phi(mpbp_ctx* c, const double* phi) {
+  if (!c || !phi) return MPBP_EINVAL;
+  c->phi.assign(phi, phi + (size_t)c->q * c->L * c->N); c->tables_dirty = true; return MPBP_OK;
+}
+extern "C" int mpbp_set_psi(mpbp_ctx* c, const double* psi) {
+  if (!c || !psi) return MPBP_EINVAL;
+  c->psi.assign(psi, psi + (size_t)c->q * c->q * c->L * c->E); c->tables_dirty = true; return MPBP_OK;
+}
+
+extern "C" int mpbp_set_messages(mpbp_ctx* c, const int32_t* bonds, const int64_t* offsets, const double* data) {
+  if (!c || !bonds || !offsets || !data) return MPBP_EINVAL;
+  hipSetDevice(c->device);
+  const int L = c->L, qq = c->q * c->q;
+  std::vector<double> slot((size_t)c->slot_doubles);
+  for (int e = 0; e < c->E; e++) {
+    const int32_t* b = bonds + (int64_t)e * (L + 1);
+    if (b[0] != 1 || b[L] != 1) return c->fail(MPBP_EINVAL, "edge %d: open-chain messages need bond 1 at both ends", e);
+    const double* src = data + offsets[e];
+    for (int t = 0; t < L; t++) {
+      if (b[t] < 1 || b[t] > c->cap || b[t + 1] > c->cap) return c->fail(MPBP_ECAPACITY, "edge %d: bond %d exceeds max_bond %d", e, std::max(b[t], b[t + 1]), c->cap);
+      const int64_t n = (int64_t)b[t] * b[t + 1] * qq;
+      memcpy(slot.data() + (int64_t)t * c->core_stride, src, sizeof(double) * n);
+      src += n;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->slot_cores(e), slot.data(), sizeof(double) * c->slot_doubles, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->slot_bonds(e), b, sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_get_bonds(mpbp_ctx* c, int32_t* bonds) {
+  if (!c || !bonds) return MPBP_EINVAL;
+  hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int e = 0; e < c->E; e++)
+    HIPCHK(c, hipMemcpy(bonds + (int64_t)e * (c->L + 1), c->slot_bonds(e), sizeof(int32_t) * (c->L + 1), hipMemcpyDeviceToHost));
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_get_messages(mpbp_ctx* c, const int64_t* offsets, double* data) {
+  if (!c || !offsets || !data) return MPBP_EINVAL;
+  hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int L = c->L, qq = c->q * c->q;
+  std::vector<double> slot((size_t)c->slot_doubles);
+  std::vector<int32_t> b(L + 1);
+  for (int e = 0; e < c->E; e++) {
+    HIPCHK(c, hipMemcpy(slot.data(), c->slot_cores(e), sizeof(double) * c->slot_doubles, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(b.data(), c->slot_bonds(e), sizeof(int32_t) * (L + 1), hipMemcpyDeviceToHost));
+    double* dst = data + offsets[e];
+    for (int t = 0; t < L; t++) {
+      const int64_t n = (int64_t)b[t] * b[t + 1] * qq;
+      memcpy(dst, slot.data() + (int64_t)t * c->core_stride, sizeof(double) * n);
+      dst += n;
+    }
+  }
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_reset_messages(mpbp_ctx* c) {
+  if (!c) return MPBP_EINVAL;
+  hipSetDevice(c->device);
+  const int L = c->L, qq = c->q * c->q;
+  // uniform normalised bond-1 message: every core = 1/(q*q) -> sum over all x of the product = 1
+  std::vector<double> slot((size_t)c->slot_doubles, 0.0);
+  for (int t = 0; t < L; t++) for (int s = 0; s < qq; s++) slot[(int64_t)t * c->core_stride + s] = 1.0 / qq;
+  std::vector<int32_t> b(L + 1, 1);
+  for (int e = 0; e < c->E; e++) {
+    HIPCHK(c, hipMemcpy(c->slot_cores(e), slot.data(), sizeof(double) * c->slot_doubles, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->slot_bonds(e), b.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice));
+  }
+  return MPBP_OK;
+}
+
+// ================================================================================================
+// table composition
+// ================================================================================================
+namespace {
+
+struct TableStore {
+  std::vector<double> data;
+  std::unordered_map<std::string, int64_t> seen;
+  int64_t add(const std::vector<double>& v) {
+    std::string key((const char*)v.data(), v.size() * sizeof(double));
+    auto it = seen.find(key);
+    if (it != seen.end()) return it->second;
+    // keep every table 32-byte aligned
+    while (data.size() % 4) data.push_back(0.0);
+    int64_t off = (int64_t)data.size();
+    data.insert(data.end(), v.begin(), v.end());
+    seen.emplace(std::move(key), off);
+    return off;
+  }
+};
+
+}  // namespace
+
+static int build_tables(mpbp_ctx* c) {
+  const int N = c->N, L = c->L, q = c->q;
+  for (int i = 0; i < N; i++) if (!c->fac[i].set) return c->fail(MPBP_EINVAL, "factor of node %d was never set (mpbp_set_factor)", i);
+  TableStore ts;
+  const int nnz = c->nnz();
+  c->pxy_off.assign(nnz, 0); c->pxy_tstride.assign(nnz, 0); c->wmsg_off.assign(nnz, 0);
+  c->wbel_off.assign(N, 0); c->init_off.assign(N, 0); c->pyy_base.assign(N, 0);
+  auto PHI = [&](int i, int t, int x) { return c->phi[x + (size_t)q * (t + (size_t)L * i)]; };
+  auto PSI = [&](int e, int t, int xs, int xd) { return c->psi[xs + (size_t)q * (xd + (size_t)q * (t + (size_t)L * e))]; };
+  for (int i = 0; i < N; i++) {
+    const NodeFactor& f = c->fac[i];
+    const int z = f.deg;
+    const int nyz = f.ny[z];
+    auto PY = [&](int t, int xn, int x, int y) { return f.prob_y[(f.nt == 1 ? 0 : (size_t)t * q * q * nyz) + xn + q * (x + (size_t)q * y)]; };
+    const int ny1 = z > 0 ? f.ny[1] : 1;
+    auto PXY = [&](int t, int k, int y, int xk, int xi) {
+      return f.prob_xy[(f.nt == 1 ? 0 : (size_t)t * z * ny1 * q * q) + (size_t)k * ny1 * q * q + y + ny1 * (xk + (size_t)q * xi)];
+    };
+    auto PYY = [&](int t, int d1, int d2, int y, int y1, int y2, int xi) {
+      const int64_t o = f.yy_off[d1 * (z + 1) + d2];
+      return f.prob_yy[(f.nt == 1 ? 0 : (size_t)t * f.yy_tblock) + o + y + f.ny[d1 + d2] * (y1 + (size_t)f.ny[d1] * (y2 + (size_t)f.ny[d2] * xi))];
+    };
+    // prob_yy blob as is (layout already [y][y1][y2][xi] per block, per time)
+    c->pyy_base[i] = ts.add(f.prob_yy);
+    // init train core [ny0][q] (time constant or not: use time 0..L-1 blocks)
+    {
+      std::vector<double> v((size_t)f.ny[0] * q * L);
+      for (int t = 0; t < L; t++)
+        for (int k = 0; k < f.ny[0] * q; k++) v[(size_t)t * f.ny[0] * q + k] = f.prob_y0[(f.nt == 1 ? 0 : (size_t)t * f.ny[0] * q) + k];
+      c->init_off[i] = ts.add(v);
+    }
+    for (int k = 0; k < z; k++) {
+      const int p = c->nbr_ptr[i] + k;
+      const int eo = c->out_edge[p];
+      // pxy (x psi of the out-edge i->k, indexed [xi][xk]): tab[t][y + ny1*(xk + q*xi)]
+      std::vector<double> v((size_t)L * ny1 * q * q);
+      for (int t = 0; t < L; t++)
+        for (int xi = 0; xi < q; xi++)
+          for (int xk = 0; xk < q; xk++)
+            for (int y = 0; y < ny1; y++)
+              v[(size_t)t * ny1 * q * q + y + ny1 * (xk + q * xi)] = PXY(t, k, y, xk, xi) * PSI(eo, t, xi, xk);
+      c->pxy_off[p] = ts.add(v); c->pxy_tstride[p] = (int64_t)ny1 * q * q;
+      // W for the message to neighbour k: prob_y_partial(x',x,xj,y1; d=z-1, k) * phi
+      const int nyc = f.ny[z - 1];     // states of the cavity accumulator
+      std::vector<double> w((size_t)L * q * q * q * nyc);
+      for (int t = 0; t < L; t++)
+        for (int y1 = 0; y1 < nyc; y1++)
+          for (int xj = 0; xj < q; xj++)
+            for (int x = 0; x < q; x++)
+              for (int xn = 0; xn < q; xn++) {
+                double val;
+                if (t == L - 1) val = PHI(i, t, x);
+                else {
+                  double s = 0.0;
+                  for (int y = 0; y < nyz; y++)
+                    for (int y2 = 0; y2 < ny1; y2++) {
+                      const double pyy = PYY(t, z - 1, 1, y, y1, y2, x);
+                      if (pyy != 0.0) s += PY(t, xn, x, y) * PXY(t, k, y2, xj, x) * pyy;
+                    }
+                  val = s * PHI(i, t, x);
+                }
+                w[(size_t)t * q * q * q * nyc + xn + q * (x + q * (xj + (size_t)q * y1))] = val;
+              }
+      c->wmsg_off[p] = ts.add(w);
+    }
+    // W for the belief: prob_y(x',x,y,z) * phi   (qj = 1)
+    {
+      std::vector<double> w((size_t)L * q * q * nyz);
+      for (int t = 0; t < L; t++)
+        for (int y = 0; y < nyz; y++)
+          for (int x = 0; x < q; x++)
+            for (int xn = 0; xn < q; xn++)
+              w[(size_t)t * q * q * nyz + xn + q * (x + (size_t)q * y)] = (t == L - 1) ? PHI(i, t, x) : PY(t, xn, x, y) * PHI(i, t, x);
+      c->wbel_off[i] = ts.add(w);
+    }
+  }
+  if (c->d_tab) { hipFree(c->d_tab); c->d_tab = nullptr; }
+  c->tab_doubles = ts.data.size();
+  HIPCHK(c, hipMalloc(&c->d_tab, sizeof(double) * std::max<size_t>(ts.data.size(), 4)));
+  HIPCHK(c, hipMemcpy(c->d_tab, ts.data.data(), sizeof(double) * ts.data.size(), hipMemcpyHostToDevice));
+  c->tables_dirty = false;
+  return MPBP_OK;
+}
+
+// ================================================================================================
+// the sweep
+// ================================================================================================
+namespace {
+
+struct OpRec { int in1, in2, out, d1, d2, node, level; };   // indices into the train table
+
+static int ensure_arena(mpbp_ctx* c, Arena& a, size_t bytes) {
+  if (a.cap >= bytes) return MPBP_OK;
+  if (a.base) { hipFree(a.base); a.base = nullptr; a.cap = 0; }
+  size_t want = bytes + (bytes >> 3) + (1 << 20);
+  hipError_t e = hipMalloc((void**)&a.base, want);
+  if (e != hipSuccess) return c->fail(MPBP_ENOMEM, "hipMalloc(%zu MiB work arena) failed: %s", want >> 20, hipGetErrorString(e));
+  a.cap = want;
+  return MPBP_OK;
+}
+
+struct EngLaunchPlan {
+  std::vector<EngProb> probs; std::vector<double> cost;
+  int cap1 = 1, cap2 = 1, ny1 = 1, ny2 = 1, ny = 1, q = 1, capout = 1;
+};
+
+static inline int r16h(int x) { return (x + 15) & ~15; }
+
+// fills cfg + returns LDS bytes and per-slot scratch doubles
+static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& cfg, size_t& lds_bytes) {
+  memset(&cfg, 0, sizeof cfg);
+  cfg.L = L; cfg.trunc = trunc;
+  const int64_t Bmax = (int64_t)pl.cap1 * pl.cap2;
+  const int nmax = pl.capout * pl.ny * pl.q;
+  cfg.Bmax = (int)Bmax; cfg.nmax = nmax;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off += (n + 15) & ~int64_t(15); return o; };
+  cfg.lf_stride = (Bmax * Bmax + 15) & ~int64_t(15);
+  cfg.off_Lf = take(cfg.lf_stride * (L + 1));
+  cfg.off_Z = take((int64_t)pl.cap1 * pl.ny1 * pl.q * pl.cap2 * Bmax);
+  cfg.off_Y = take((int64_t)r16h((int)(Bmax * pl.ny * pl.q)) * r16h((int)Bmax));
+  cfg.off_C0 = take((int64_t)pl.capout * Bmax);
+  cfg.off_C1 = take((int64_t)pl.capout * Bmax);
+  cfg.off_T1 = take((int64_t)pl.cap1 * pl.ny1 * pl.q * pl.capout * pl.cap2);
+  cfg.off_Nt = take((int64_t)nmax * Bmax);
+  cfg.off_Mt = take((int64_t)r16h((int)Bmax) * r16h(nmax));
+  cfg.off_JA = take((int64_t)nmax * nmax);
+  cfg.off_JV = take((int64_t)nmax * nmax);
+  const int64_t nA1 = (int64_t)pl.cap1 * pl.cap1 * pl.ny1 * pl.q, nA2 = (int64_t)pl.cap2 * pl.cap2 * pl.ny2 * pl.q;
+  const int64_t nE = (int64_t)pl.q * pl.cap2 * pl.ny * pl.cap2 * pl.ny1;
+  cfg.off_A1c = take(nA1); cfg.off_A2c = take(nA2); cfg.off_E = take(nE);
+  cfg.slot_doubles = off;
+  // LDS: [gemm][qr][misc][rdim] fixed, then union{cores+E, jacobi} if they fit in 150 KiB
+  int64_t l = 0;
+  auto ltake = [&](int64_t n) { int64_t o = l; l += (n + 3) & ~int64_t(3); return (int32_t)o; };
+  cfg.lds_gemm = ltake(wg::GM_LDS_DOUBLES);
+  cfg.lds_qr = ltake(wg::QR_LDS_DOUBLES);
+  cfg.lds_misc = ltake(32 + nmax + (nmax + 1) / 2 + 4);
+  cfg.lds_rdim = ltake((L + 2 + 1) / 2 + 2);
+  const int64_t budget = (150 * 1024) / 8;
+  const int64_t base = l;
+  const int64_t coresE = ((nA1 + 3) & ~3) + ((nA2 + 3) & ~3) + ((nE + 3) & ~3);
+  const int64_t jac = 2 * (((int64_t)nmax * nmax + 3) & ~3);
+  bool cores_fit = base + coresE <= budget, jac_fit = base + jac <= budget;
+  if (cores_fit) { int64_t o = base; cfg.lds_A1c = (int32_t)o; o += (nA1 + 3) & ~3; cfg.lds_A2c = (int32_t)o; o += (nA2 + 3) & ~3; cfg.lds_E = (int32_t)o; }
+  else { cfg.lds_A1c = cfg.lds_A2c = cfg.lds_E = -1; }
+  if (jac_fit) { cfg.lds_JA = (int32_t)base; cfg.lds_JV = (int32_t)(base + (((int64_t)nmax * nmax + 3) & ~3)); }
+  else { cfg.lds_JA = cfg.lds_JV = -1; }
+  int64_t top = base + std::max(cores_fit ? coresE : 0, jac_fit ? jac : 0);
+  lds_bytes = (size_t)top * 8;
+}
+
+}  // namespace
+
+static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool count_as_orth, float* ms_orth, int* n_orth) {
+  const int nprob = (int)pl.probs.size();
+  if (nprob == 0) return MPBP_OK;
+  // sort by decreasing cost (longest first)
+  std::vector<int> idx(nprob);
+  for (int i = 0; i < nprob; i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return pl.cost[a] > pl.cost[b]; });
+  std::vector<EngProb> sorted(nprob);
+  for (int i = 0; i < nprob; i++) sorted[i] = pl.probs[idx[i]];
+  EngCfg cfg; size_t lds_bytes;
+  plan_cfg(pl, c->L, trunc, cfg, lds_bytes);
+  HIPCHK(c, hipFuncSetAttribute((const void*)eng_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  int per_cu = 1;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, eng_kernel, WG_THREADS, lds_bytes);
+  if (per_cu < 1) per_cu = 1;
+  int nslots = std::min(nprob, c->num_cu * per_cu);
+  // scratch: bounded by a budget; fewer slots if needed
+  size_t slot_bytes = (size_t)cfg.slot_doubles * 8;
+  size_t freeb = 0, totb = 0;
+  hipMemGetInfo(&freeb, &totb);
+  size_t budget = c->scratch.cap + (size_t)(freeb * 0.85);
+  while (nslots > 1 && (size_t)nslots * slot_bytes > budget) nslots = (nslots + 1) / 2;
+  int rc = ensure_arena(c, c->scratch, (size_t)nslots * slot_bytes + sizeof(EngProb) * nprob + 4096);
+  if (rc != MPBP_OK) return rc;
+  double* d_scr = (double*)c->scratch.base;
+  EngProb* d_probs = (EngProb*)(c->scratch.base + (((size_t)nslots * slot_bytes + 255) & ~size_t(255)));
+  HIPCHK(c, hipMemcpyAsync(d_probs, sorted.data(), sizeof(EngProb) * nprob, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (count_as_orth && c->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
+  hipLaunchKernelGGL(eng_kernel, dim3(nslots), dim3(WG_THREADS), lds_bytes, c->stream, d_probs, nprob, c->d_counter, cfg, d_scr, c->d_stats);
+  HIPCHK(c, hipGetLastError());
+  if (e0) {
+    hipEventRecord(e1, c->stream); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_orth += ms; *n_orth += 1;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  // the host vectors `sorted` must outlive the async copy
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_trunc trunc, double damp, mpbp_stats* stats) {
+  if (!c) return MPBP_EINVAL;
+  if (n_nodes < 0 || (n_nodes > 0 && !nodes)) return c->fail(MPBP_EINVAL, "bad node list");
+  if (!(damp >= 0.0 && damp < 1.0)) return c->fail(MPBP_EINVAL, "damp must satisfy 0 <= damp < 1 (reference src/recursive_bp_factor.jl:169)");
+  if (damp != 0.0) return c->fail(MPBP_EUNSUPPORTED, "damping (set_msg! with damp > 0) is not implemented on the device path yet");
+  if (trunc.kind < 0 || trunc.kind > 3) return c->fail(MPBP_EINVAL, "unknown truncation kind %d", trunc.kind);
+  if (trunc.kind != MPBP_TRUNC_THRESH && trunc.mprime < 1) return c->fail(MPBP_EINVAL, "mprime must be >= 1");
+  hipSetDevice(c->device);
+  if (c->tables_dirty) { int rc = build_tables(c); if (rc != MPBP_OK) return rc; }
+  const int L = c->L, q = c->q, cap = c->cap;
+  std::vector<char> seen(c->N, 0);
+  for (int k = 0; k < n_nodes; k++) {
+    if (nodes[k] < 0 || nodes[k] >= c->N) return c->fail(MPBP_EINVAL, "node id %d out of range", nodes[k]);
+    if (seen[nodes[k]]) return c->fail(MPBP_EINVAL, "node %d listed twice", nodes[k]);
+    seen[nodes[k]] = 1;
+  }
+  hipEvent_t ev0, ev1;
+  hipEventCreate(&ev0); hipEventCreate(&ev1);
+  hipEventRecord(ev0, c->stream);
+  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(EngStats), c->stream));
+  float ms_orth = 0.f; int n_orth = 0;
+
+  // ---------------------------------------------------------------- plan: trains, ops, levels
+  struct TrainSpec { int cap, ny, qphys; int d; int level; int64_t tab_off; bool is_init; int node; };
+  std::vector<TrainSpec> specs;     // scratch trains to allocate
+  std::vector<DevTrain> tr;         // filled after allocation (same indexing)
+  auto new_train = [&](int capv, int ny, int qphys, int d, int level) {
+    specs.push_back({capv, ny, qphys, d, level, 0, false, -1});
+    return (int)specs.size() - 1;
+  };
+  std::vector<OpRec> ops;
+  struct NodePlan { int node; std::vector<int> src, dest; int full; int init; };
+  std::vector<NodePlan> plans(n_nodes);
+  int maxlevel = 0;
+  for (int k = 0; k < n_nodes; k++) {
+    const int i = nodes[k];
+    const NodeFactor& f = c->fac[i];
+    const int z = f.deg;
+    NodePlan& P = plans[k];
+    P.node = i;
+    P.init = new_train(1, f.ny[0], q, 0, 0);
+    specs[P.init].is_init = true; specs[P.init].node = i;
+    for (int j = 0; j < z; j++) P.src.push_back(new_train(cap, f.ny[1], q, 1, 0));
+    auto op = [&](int a, int b) {
+      const int d1 = specs[a].d, d2 = specs[b].d;
+      const int lev = std::max(specs[a].level, specs[b].level) + 1;
+      const int o = new_train(cap, f.ny[d1 + d2], q, d1 + d2, lev);
+      ops.push_back({a, b, o, d1, d2, i, lev});
+      maxlevel = std::max(maxlevel, lev);
+      return o;
+    };
+    // CavityTools.cavity (3z-2 calls in this order)
+    P.dest.assign(z, -1);
+    if (z == 0) P.full = P.init;
+    else if (z == 1) { P.dest[0] = P.init; P.full = op(P.src[0], P.init); }
+    else {
+      P.dest[0] = P.src[0];
+      for (int j = 1; j < z; j++) P.dest[j] = op(P.dest[j - 1], P.src[j]);
+      P.full = op(P.dest[z - 1], P.init);
+      int right = P.init;
+      for (int j = z - 1; j >= 1; j--) { P.dest[j] = op(P.dest[j - 1], right); right = op(P.src[j], right); }
+      P.dest[0] = right;
+    }
+  }
+  // finalisation trains: ctilde (bond 2*cap... = q*cap), engine output (message), belief ctilde
+  struct FinRec { int k, j, p, src, ct, out; };
+  std::vector<FinRec> fins; std::vector<FinRec> bels;
+  const int capct = q * cap;
+  for (int k = 0; k < n_nodes; k++) {
+    NodePlan& P = plans[k];
+    const int i = P.node; const int z = c->fac[i].deg;
+    for (int j = 0; j < z; j++) {
+      const int p = c->nbr_ptr[i] + j;
+      const int ct = new_train(capct, q * q, 1, 0, 0);      // explicit cores: ny = q*qj, engine q = 1
+      const int out = new_train(cap, q * q, 1, 0, 0);
+      fins.push_back({k, j, p, P.dest[j], ct, out});
+    }
+    const int ctb = new_train(capct, q, 1, 0, 0);           // belief: qj = 1
+    bels.push_back({k, -1, -1, P.full, ctb, -1});
+  }
+  // ---------------------------------------------------------------- allocate the arena
+  c->arena.reset();
+  tr.resize(specs.size());
+  auto bytes_of = [&](const TrainSpec& s) {
+    int64_t stride = ((int64_t)s.cap * s.cap * s.ny * s.qphys + 3) & ~int64_t(3);
+    return std::pair<int64_t, int64_t>(stride, stride * L);
+  };
+  for (int pass = 0; pass < 2; pass++) {
+    c->arena.reset();
+    bool ok = true;
+    for (size_t s = 0; s < specs.size(); s++) {
+      tr[s].cap = specs[s].cap; tr[s].ny = specs[s].ny; tr[s].d = specs[s].d; tr[s].level = specs[s].level;
+      if (specs[s].is_init) {
+        // the init train (src/recursive_bp_factor.jl:133-138) is read straight from the table blob:
+        // cores [1,1,ny0,q] per time = prob_y0, all bonds 1, z = 1
+        const int i = specs[s].node;
+        tr[s].cores = c->d_tab + c->init_off[i]; tr[s].stride = (int64_t)c->fac[i].ny[0] * q;
+        tr[s].bonds = c->d_ones; tr[s].logz = c->d_one + 1;
+        continue;
+      }
+      auto bs = bytes_of(specs[s]);
+      tr[s].stride = bs.first;
+      tr[s].cores = (double*)c->arena.take(sizeof(double) * bs.second);
+      tr[s].bonds = (int32_t*)c->arena.take(sizeof(int32_t) * (L + 2));
+      tr[s].logz = (double*)c->arena.take(sizeof(double) * 2);
+      if (!tr[s].cores || !tr[s].bonds || !tr[s].logz) ok = false;
+    }
+    if (ok) break;
+    if (pass == 1) return c->fail(MPBP_ENOMEM, "work arena too small");
+    int rc = ensure_arena(c, c->arena, c->arena.want + (1 << 20));
+    if (rc != MPBP_OK) return rc;
+  }
+  // ---------------------------------------------------------------- prep: sources from the messages
+  {
+    std::vector<PrepProb> pp;
+    for (int k = 0; k < n_nodes; k++) {
+      const int i = plans[k].node; const NodeFactor& f = c->fac[i];
+      for (int j = 0; j < f.deg; j++) {
+        const int p = c->nbr_ptr[i] + j;
+        const int ein = c->in_edge[p];
+        DevTrain& o = tr[plans[k].src[j]];
+        PrepProb P{};
+        P.msg = c->slot_cores(ein); P.mbond = c->slot_bonds(ein); P.mstride = c->core_stride;
+        P.tab = c->d_tab + c->pxy_off[p]; P.tab_tstride = c->pxy_tstride[p];
+        P.out = o.cores; P.obond = o.bonds; P.ostride = o.stride; P.ologz = o.logz; P.ny1 = f.ny[1]; P.q = q;
+        pp.push_back(P);
+      }
+    }
+    if (!pp.empty()) {
+      int rc = ensure_arena(c, c->scratch, sizeof(PrepProb) * pp.size() + 4096);
+      if (rc != MPBP_OK) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->scratch.base, pp.data(), sizeof(PrepProb) * pp.size(), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(prep_kernel, dim3(L, (unsigned)pp.size()), dim3(256), 0, c->stream, (const PrepProb*)c->scratch.base, L);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+  }
+  // ---------------------------------------------------------------- cavity ops, level by level
+  for (int lev = 1; lev <= maxlevel; lev++) {
+    EngLaunchPlan pl; pl.q = q; pl.capout = cap;
+    for (const OpRec& o : ops) {
+      if (o.level != lev) continue;
+      const NodeFactor& f = c->fac[o.node];
+      const DevTrain &a = tr[o.in1], &b = tr[o.in2], &out = tr[o.out];
+      EngProb P{};
+      P.A1 = a.cores; P.bond1 = a.bonds; P.stride1 = a.stride; P.ny1 = a.ny;
+      P.A2 = b.cores; P.bond2 = b.bonds; P.stride2 = b.stride; P.ny2 = b.ny;
+      P.logz1 = a.logz; P.logz2 = b.logz;
+      P.pyy = c->d_tab + c->pyy_base[o.node] + f.yy_off[o.d1 * (f.deg + 1) + o.d2];
+      P.pyy_tstride = f.nt == 1 ? 0 : f.yy_tblock;
+      P.ny = out.ny; P.q = q; P.mirror = 0; P.cap_out = cap;
+      P.out = out.cores; P.obond = out.bonds; P.ostride = out.stride; P.ologz = out.logz;
+      pl.probs.push_back(P);
+      const double B = (double)a.cap * b.cap;
+      pl.cost.push_back(B * B * B * out.ny);
+      pl.cap1 = std::max(pl.cap1, a.cap); pl.cap2 = std::max(pl.cap2, b.cap);
+      pl.ny1 = std::max(pl.ny1, a.ny); pl.ny2 = std::max(pl.ny2, b.ny); pl.ny = std::max(pl.ny, out.ny);
+    }
+    int rc = launch_engine(c, pl, trunc, true, &ms_orth, &n_orth);
+    if (rc != MPBP_OK) return rc;
+  }
+  // ---------------------------------------------------------------- finalise messages + beliefs
+  {
+    std::vector<CtProb> cps;
+    for (const FinRec& fr : fins) {
+      const int i = plans[fr.k].node; const NodeFactor& f = c->fac[i];
+      const DevTrain &s = tr[fr.src], &ct = tr[fr.ct];
+      CtProb P{};
+      P.in = s.cores; P.ibond = s.bonds; P.istride = s.stride; P.ilogz = s.logz; P.ny = s.ny;
+      P.W = c->d_tab + c->wmsg_off[fr.p]; P.q = q; P.qj = q;
+      P.out = ct.cores; P.obond = ct.bonds; P.ostride = ct.stride; P.ologz = ct.logz;
+      (void)f;
+      cps.push_back(P);
+    }
+    for (const FinRec& fr : bels) {
+      const int i = plans[fr.k].node;
+      const DevTrain &s = tr[fr.src], &ct = tr[fr.ct];
+      CtProb P{};
+      P.in = s.cores; P.ibond = s.bonds; P.istride = s.stride; P.ilogz = s.logz; P.ny = s.ny;
+      P.W = c->d_tab + c->wbel_off[i]; P.q = q; P.qj = 1;
+      P.out = ct.cores; P.obond = ct.bonds; P.ostride = ct.stride; P.ologz = ct.logz;
+      cps.push_back(P);
+    }
+    if (!cps.empty()) {
+      int rc = ensure_arena(c, c->scratch, sizeof(CtProb) * cps.size() + 4096);
+      if (rc != MPBP_OK) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->scratch.base, cps.data(), sizeof(CtProb) * cps.size(), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(ctilde_kernel, dim3(L, (unsigned)cps.size()), dim3(256), 0, c->stream, (const CtProb*)c->scratch.base, L);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    // engine (mirror): mpem2 |> compress!(:left) |> normalize_eachmatrix!
+    EngLaunchPlan pl; pl.q = 1; pl.capout = cap; pl.cap1 = capct; pl.cap2 = 1; pl.ny1 = q * q; pl.ny2 = 1; pl.ny = q * q;
+    for (const FinRec& fr : fins) {
+      const DevTrain &ct = tr[fr.ct], &out = tr[fr.out];
+      EngProb P{};
+      P.A1 = ct.cores; P.bond1 = ct.bonds; P.stride1 = ct.stride; P.ny1 = q * q;
+      P.A2 = c->d_one; P.bond2 = c->d_ones; P.stride2 = 0; P.ny2 = 1;
+      P.logz1 = ct.logz; P.logz2 = nullptr;
+      P.pyy = c->d_ident; P.pyy_tstride = 0;
+      P.ny = q * q; P.q = 1; P.mirror = 1; P.cap_out = cap;
+      P.out = out.cores; P.obond = out.bonds; P.ostride = out.stride; P.ologz = out.logz;
+      pl.probs.push_back(P); pl.cost.push_back(1.0);
+    }
+    int rc = launch_engine(c, pl, trunc, false, &ms_orth, &n_orth);
+    if (rc != MPBP_OK) return rc;
+    // env: normalize! the messages into the slab; beliefs marginals + log z_i
+    std::vector<EnvProb> eps;
+    size_t rv_doubles = 0;
+    std::vector<size_t> rv_off;
+    for (const FinRec& fr : fins) {
+      const int i = plans[fr.k].node; const int z = c->fac[i].deg;
+      const int eo = c->out_edge[fr.p];
+      // last occurrence of an aliased out-edge wins (reference src/recursive_bp_factor.jl:154-159)
+      bool last = true;
+      for (int j2 = fr.j + 1; j2 < z; j2++) if (c->out_edge[c->nbr_ptr[i] + j2] == eo) last = false;
+      const DevTrain& out = tr[fr.out];
+      EnvProb P{};
+      P.in = out.cores; P.ibond = out.bonds; P.istride = out.stride; P.ilogz = out.logz; P.p = q * q;
+      P.dst = last ? c->slot_cores(eo) : nullptr; P.dbond = last ? c->slot_bonds(eo) : nullptr; P.dstride = c->core_stride;
+      P.marg = nullptr; P.logz_out = c->d_logz_pos + fr.p; P.bmax = cap;
+      rv_off.push_back(rv_doubles); rv_doubles += (size_t)(L + 1) * cap;
+      eps.push_back(P);
+    }
+    for (const FinRec& fr : bels) {
+      const int i = plans[fr.k].node;
+      const DevTrain& ct = tr[fr.ct];
+      EnvProb P{};
+      P.in = ct.cores; P.ibond = ct.bonds; P.istride = ct.stride; P.ilogz = ct.logz; P.p = q;
+      P.dst = nullptr; P.dbond = nullptr; P.dstride = 0;
+      P.marg = c->d_beliefs + (size_t)q * L * i; P.logz_out = c->d_logz_node + i; P.bmax = capct;
+      rv_off.push_back(rv_doubles); rv_doubles += (size_t)(L + 1) * capct;
+      eps.push_back(P);
+    }
+    if (capct > 256) return c->fail(MPBP_EUNSUPPORTED, "q*max_bond > 256 not supported by the scan kernels yet");
+    if (!eps.empty()) {
+      rc = ensure_arena(c, c->scratch, sizeof(EnvProb) * eps.size() + sizeof(double) * rv_doubles + 8192);
+      if (rc != MPBP_OK) return rc;
+      double* rvbase = (double*)(c->scratch.base + ((sizeof(EnvProb) * eps.size() + 255) & ~size_t(255)));
+      for (size_t s = 0; s < eps.size(); s++) eps[s].rvec = rvbase + rv_off[s];
+      HIPCHK(c, hipMemcpyAsync(c->scratch.base, eps.data(), sizeof(EnvProb) * eps.size(), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(env_kernel, dim3((unsigned)eps.size()), dim3(256), 0, c->stream, (const EnvProb*)c->scratch.base, L);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+  }
+  // ---------------------------------------------------------------- f[i] (src/recursive_bp_factor.jl:163)
+  hipEventRecord(ev1, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->h_logz_node.data(), c->d_logz_node, sizeof(double) * c->N, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(c->h_logz_pos.data(), c->d_logz_pos, sizeof(double) * c->nnz(), hipMemcpyDeviceToHost));
+  for (int k = 0; k < n_nodes; k++) {
+    const int i = nodes[k]; const int z = c->fac[i].deg;
+    double s = 0.0;
+    for (int p = c->nbr_ptr[i]; p < c->nbr_ptr[i + 1]; p++) s += c->h_logz_pos[p];
+    c->h_f[i] = (z / 2.0 - 1.0) * c->h_logz_node[i] - 0.5 * s;
+  }
+  EngStats hs;
+  HIPCHK(c, hipMemcpy(&hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost));
+  float ms = 0; hipEventElapsedTime(&ms, ev0, ev1);
+  hipEventDestroy(ev0); hipEventDestroy(ev1);
+  mpbp_stats st{};
+  { double v; unsigned long long b = hs.maxerr_bits; memcpy(&v, &b, 8); st.maxerr = v; }
+  st.n_compress = (int64_t)hs.n_compress; st.nan_flag = hs.nan_flag; st.capacity_flag = hs.capacity_flag;
+  st.jacobi_not_converged = hs.jacobi_fail; st.ms_total = ms; st.ms_orth = ms_orth; st.n_orth_launches = n_orth;
+  c->last = st;
+  if (stats) *stats = st;
+  if (hs.capacity_flag) return c->fail(MPBP_ECAPACITY, "a truncated bond exceeded max_bond=%d; results were clamped", cap);
+  return MPBP_OK;
+}
+
+// ================================================================================================
+// observables
+// ================================================================================================
+extern "C" int mpbp_beliefs(mpbp_ctx* c, double* out) {
+  if (!c || !out) return MPBP_EINVAL;
+  hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->d_beliefs, sizeof(double) * c->q * c->L * c->N, hipMemcpyDeviceToHost));
+  return MPBP_OK;
+}
+extern "C" int mpbp_free_energy(mpbp_ctx* c, double* f) {
+  if (!c || !f) return MPBP_EINVAL;
+  memcpy(f, c->h_f.data(), sizeof(double) * c->N);
+  return MPBP_OK;
+}
+extern "C" int mpbp_logz(mpbp_ctx* c, double* ln, double* lm) {
+  if (!c) return MPBP_EINVAL;
+  if (ln) memcpy(ln, c->h_logz_node.data(), sizeof(double) * c->N);
+  if (lm) {
+    // per edge: value of the last neighbour position writing that edge
+    for (int e = 0; e < c->E; e++) lm[e] = 0.0;
+    for (int p = 0; p < c->nnz(); p++) lm[c->out_edge[p]] = c->h_logz_pos[p];
+  }
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_pair_beliefs(mpbp_ctx* c, double* out, double* logz_pair) {
+  if (!c || !out) return MPBP_EINVAL;
+  hipSetDevice(c->device);
+  const int L = c->L, q = c->q, cap = c->cap, E = c->E;
+  // reverse edge: edge e = out_edge[p] of node i at position p pairs with in_edge[p] (the message k->i)
+  std::vector<int> rev(E, -1);
+  for (int p = 0; p < c->nnz(); p++) rev[c->out_edge[p]] = c->in_edge[p];
+  for (int e = 0; e < E; e++) if (rev[e] < 0) return c->fail(MPBP_EINVAL, "edge %d is nobody's out-edge", e);
+  const size_t per = (size_t)(L + 1) * cap * cap + 3 * (size_t)cap * cap;
+  const size_t outd = (size_t)q * q * L * E;
+  int rc = ensure_arena(c, c->scratch, sizeof(PairProb) * E + sizeof(double) * (per * E + outd + E) + sizeof(double) * q * q * L * E + 16384);
+  if (rc != MPBP_OK) return rc;
+  char* base = c->scratch.base;
+  PairProb* d_p = (PairProb*)base; base += (sizeof(PairProb) * E + 255) & ~size_t(255);
+  double* d_out = (double*)base; base += sizeof(double) * outd;
+  double* d_lz = (double*)base; base += (sizeof(double) * E + 255) & ~size_t(255);
+  double* d_psi = (double*)base; base += sizeof(double) * q * q * L * E;
+  double* d_scr = (double*)base;
+  HIPCHK(c, hipMemcpyAsync(d_psi, c->psi.data(), sizeof(double) * q * q * L * E, hipMemcpyHostToDevice, c->stream));
+  std::vector<PairProb> pp(E);
+  for (int e = 0; e < E; e++) {
+    PairProb P{};
+    P.aij = c->slot_cores(e); P.bij = c->slot_bonds(e); P.aji = c->slot_cores(rev[e]); P.bji = c->slot_bonds(rev[e]);
+    P.stride = c->core_stride; P.psi = d_psi + (size_t)q * q * L * e; P.out = d_out + (size_t)q * q * L * e; P.logz = d_lz + e;
+    P.scratch = d_scr + per * e; P.q = q; P.cap = cap;
+    pp[e] = P;
+  }
+  HIPCHK(c, hipMemcpyAsync(d_p, pp.data(), sizeof(PairProb) * E, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(pair_kernel, dim3(E), dim3(256), 0, c->stream, (const PairProb*)d_p, L);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, d_out, sizeof(double) * outd, hipMemcpyDeviceToHost));
+  if (logz_pair) HIPCHK(c, hipMemcpy(logz_pair, d_lz, sizeof(double) * E, hipMemcpyDeviceToHost));
+  return MPBP_OK;
+}
+
+// ================================================================================================
+// self tests of the device building blocks
+// ================================================================================================
+static int st_fail(const char* what, hipError_t e) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); return MPBP_EHIP; }
+#define STCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return st_fail(#call, e_); } while (0)
+
+extern "C" int mpbp_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, const double* A, const double* B, double* C) {
+  STCHK(hipSetDevice(device));
+  double *dA, *dB, *dC;
+  STCHK(hipMalloc(&dA, sizeof(double) * M * K)); STCHK(hipMalloc(&dB, sizeof(double) * K * N)); STCHK(hipMalloc(&dC, sizeof(double) * M * N));
+  STCHK(hipMemcpy(dA, A, sizeof(double) * M * K, hipMemcpyHostToDevice));
+  STCHK(hipMemcpy(dB, B, sizeof(double) * K * N, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(st_gemm_kernel, dim3(1), dim3(WG_THREADS), wg::GM_LDS_DOUBLES * 8, 0, M, N, K, dA, dB, dC);
+  STCHK(hipGetLastError()); STCHK(hipDeviceSynchronize());
+  STCHK(hipMemcpy(C, dC, sizeof(double) * M * N, hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(dB); hipFree(dC);
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_selftest_qr(int32_t device, int32_t rows, int32_t cols, const double* A, double* R) {
+  STCHK(hipSetDevice(device));
+  const int ld = (rows + 15) & ~15, c16 = (cols + 15) & ~15;
+  std::vector<double> Y((size_t)ld * c16, 0.0);
+  for (int j = 0; j < cols; j++) for (int i = 0; i < rows; i++) Y[i + (size_t)ld * j] = A[i + (size_t)rows * j];
+  double* dY;
+  STCHK(hipMalloc(&dY, sizeof(double) * Y.size()));
+  STCHK(hipMemcpy(dY, Y.data(), sizeof(double) * Y.size(), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), wg::QR_LDS_DOUBLES * 8, 0, dY, ld, rows, cols);
+  STCHK(hipGetLastError()); STCHK(hipDeviceSynchronize());
+  STCHK(hipMemcpy(Y.data(), dY, sizeof(double) * Y.size(), hipMemcpyDeviceToHost));
+  const int k = std::min(rows, cols);
+  for (int j = 0; j < cols; j++) for (int i = 0; i < k; i++) R[i + (size_t)k * j] = (j >= i) ? Y[i + (size_t)ld * j] : 0.0;
+  hipFree(dY);
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, const double* A, double* sigma, double* V) {
+  STCHK(hipSetDevice(device));
+  double *dA, *dV, *dS; int* dW;
+  STCHK(hipMalloc(&dA, sizeof(double) * rows * cols)); STCHK(hipMalloc(&dV, sizeof(double) * cols * cols));
+  STCHK(hipMalloc(&dS, sizeof(double) * cols)); STCHK(hipMalloc(&dW, sizeof(int)));
+  STCHK(hipMemcpy(dA, A, sizeof(double) * rows * cols, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(st_svd_kernel, dim3(1), dim3(WG_THREADS), 64 * 8, 0, dA, rows, cols, dV, dS, dW);
+  STCHK(hipGetLastError()); STCHK(hipDeviceSynchronize());
+  STCHK(hipMemcpy(sigma, dS, sizeof(double) * cols, hipMemcpyDeviceToHost));
+  STCHK(hipMemcpy(V, dV, sizeof(double) * cols * cols, hipMemcpyDeviceToHost));
+  int sw = 0; STCHK(hipMemcpy(&sw, dW, sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(dV); hipFree(dS); hipFree(dW);
+  return sw < 0 ? MPBP_EUNSUPPORTED : MPBP_OK;
+}

@@ -1,0 +1,63 @@
+"""Device building blocks (MFMA GEMM with index maps, R-only blocked Householder QR, one-sided Jacobi)
+against numpy, through the C-ABI self-test entry points."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mpbp_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (20, 37, 20), (80, 300, 20), (40, 129, 40), (97, 200, 33), (200, 64, 400)])
+def test_gemm_mfma_f64_asymmetric(M, N, K):
+    rng = np.random.default_rng(1)
+    A = np.asfortranarray(rng.standard_normal((M, K)))
+    B = np.asfortranarray(rng.standard_normal((K, N)))
+    Cc = np.zeros((M, N), order="F")
+    rc = mpbp_amd._lib.lib().mpbp_selftest_gemm(0, M, N, K, _dp(A), _dp(B), _dp(Cc))
+    assert rc == 0
+    ref = A @ B
+    assert np.abs(Cc - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()) * K
+
+
+@pytest.mark.parametrize("rows,cols", [(4, 16), (16, 16), (64, 16), (100, 37), (256, 64), (1600, 400), (80, 400), (33, 80)])
+def test_qr_r_only(rows, cols):
+    rng = np.random.default_rng(2)
+    A = np.asfortranarray(rng.standard_normal((rows, cols)))
+    if rows > 40:
+        A[:, 3] = A[:, 1] * 2.0          # exact rank deficiency must not break Householder
+    k = min(rows, cols)
+    R = np.zeros((k, cols), order="F")
+    rc = mpbp_amd._lib.lib().mpbp_selftest_qr(0, rows, cols, _dp(A), _dp(R))
+    assert rc == 0
+    # R is unique up to row signs: compare Gram matrices and |R| with numpy's
+    G = A.T @ A
+    assert np.abs(R.T @ R - G).max() < 1e-11 * np.abs(G).max()
+    Rn = np.linalg.qr(A, mode="r")
+    sgn = np.sign(np.diag(Rn[:k, :k])) * np.sign(np.diag(R[:k, :k]))
+    sgn[sgn == 0] = 1
+    assert np.abs(R * sgn[:, None] - Rn[:k]).max() < 1e-9 * np.abs(Rn).max() or rows > 40
+
+
+@pytest.mark.parametrize("m,n", [(8, 8), (40, 80), (80, 80), (20, 33)])
+def test_jacobi_right_singular_vectors(m, n):
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((m, n)) @ np.diag(np.logspace(0, -9, n))
+    Af = np.asfortranarray(A.copy())
+    sig = np.zeros(n)
+    V = np.zeros((n, n), order="F")
+    rc = mpbp_amd._lib.lib().mpbp_selftest_svd(0, m, n, _dp(Af), _dp(sig), _dp(V))
+    assert rc == 0
+    s_ref = np.linalg.svd(A, compute_uv=False)
+    s = np.sort(sig)[::-1]
+    assert np.abs(s[:len(s_ref)] - s_ref).max() < 1e-12 * s_ref[0]
+    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+    # A V has orthogonal columns with norms sigma
+    W = A @ V
+    assert np.abs(W.T @ W - np.diag(sig ** 2)).max() < 1e-12 * s_ref[0] ** 2

@@ -1,0 +1,170 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same inputs, and with the
+reference's own known answers.  Tolerance: 1e-6 relative (BASELINE.json north_star); most cases are
+checked far tighter because the device algorithm is backward stable."""
+import networkx as nx
+import numpy as np
+import pytest
+
+import mpbp_amd as M
+from oracle import factors as OF
+from oracle import mpbp as O
+from oracle import tensor_trains as OT
+from oracle.exact import exact_marginals, exact_pair_marginals, exact_prob
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def _flat(bb):
+    return np.array([p for b in bb for p in b])
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_known_answer_sis_infinite_graph_gpu():
+    """reference test/sis_infinite_graph.jl:1-30 on the device path."""
+    T, k, gam, lam, rho = 6, 3, 0.1, 0.1, 0.2
+    phi = [np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)]
+    bp = M.mpbp_infinite_graph(k, [M.SISFactor(lam, rho)] * (T + 1), 2, phi, max_bond=10)
+    it, cb = M.iterate(bp, maxiter=200, svd_trunc=M.TruncBond(10), tol=1e-14)
+    ref = [[0.9000000001671186, 0.0999999998328814],
+           [0.8932690998131098, 0.10673090018689023],
+           [0.8899420329322244, 0.11005796706777556],
+           [0.8884643888492034, 0.11153561115079656],
+           [0.8880305235706524, 0.1119694764293476],
+           [0.8882121515614524, 0.11178784843854758],
+           [0.8887717202217936, 0.1112282797782064]]
+    np.testing.assert_allclose(np.array(M.beliefs(bp)[0]), np.array(ref), rtol=1.5e-8, atol=0)
+
+
+def _sis_star_inputs(T=3):
+    A = np.array([[0, 1, 1, 1], [1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0]])
+    lam, rho, gam, alpha = 0.5, 0.4, 0.5, 0.1
+    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(4)]
+    rng = np.random.default_rng(111)
+    for i in range(4):
+        phi[i][T] = np.array([1.0, 0.0]) if rng.random() < 0.5 else np.array([0.0, 1.0])
+    return A, lam, rho, alpha, phi, T
+
+
+@pytest.mark.parametrize("schedule", ["sequential", "colored", "jacobi"])
+def test_sis_small_tree_exact_gpu(schedule):
+    """reference test/sis_small_tree.jl:4-50 against brute-force enumeration (oracle/exact.py)."""
+    A, lam, rho, alpha, phi, T = _sis_star_inputs()
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, 2, T, phi=phi, max_bond=16)
+    tr = M.TruncBondMax(4)
+    M.iterate(bp, maxiter=10, svd_trunc=tr, schedule=schedule)
+    og = O.IndexedBiDiGraph(A)
+    obp = O.mpbp(og, [[OF.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, [2] * 4, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+    pb, _ = M.pair_beliefs(bp)
+    assert _rel(_flat(pb), _flat(exact_pair_marginals(obp, p))) < 1e-9
+    assert tr.maxerr < 1e-7
+
+
+def _loopy(N, T, lam, rho, gam, seed=0):
+    G = nx.random_regular_graph(3, N, seed=seed)
+    A = nx.to_numpy_array(G)
+    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    return A, phi
+
+
+@pytest.mark.parametrize("N,T,Mb,sweeps", [(8, 5, 4, 3), (16, 10, 8, 3)])
+def test_sis_loopy_jacobi_sweeps_match_oracle(N, T, Mb, sweeps):
+    """Binding truncation on a loopy 3-regular graph: every Jacobi sweep must reproduce the oracle's
+    beliefs, pair beliefs and free energy (SURVEY 8d parity read-outs)."""
+    lam, rho, gam = 0.1, 0.05, 0.1
+    A, phi = _loopy(N, T, lam, rho, gam)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    for s in range(sweeps):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+        # per-node free-energy terms (the sum cancels to ~0 without observations)
+        import ctypes as C
+        f = np.zeros(N)
+        bp._L.mpbp_free_energy(bp._h, f.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.abs(f - obp.f).max() < RTOL * max(1.0, np.abs(obp.f).max()), f"sweep {s}"
+    pb, lz = M.pair_beliefs(bp)
+    opb, olz = O.pair_beliefs(obp)
+    assert _rel(_flat(pb), _flat(opb)) < RTOL
+    assert np.abs(lz - olz).max() < RTOL * max(1.0, np.abs(olz).max())
+    assert (bp.bonds() <= Mb).all()
+    ob = np.array([m.bonds for m in obp.mu])
+    assert np.array_equal(bp.bonds(), ob)
+
+
+def test_glauber_small_tree_gpu():
+    """reference test/glauber_small_tree.jl:3-72 structure (star of 4 + isolated node, T=2,
+    TruncBondThresh(10)); HomogeneousGlauberFactor with growing nstates = l+1."""
+    T = 2
+    J = np.array([[0, 1, 0, 0, 0], [1, 0, 1, 1, 0], [0, 1, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 0, 0, 0]], float)
+    rng = np.random.default_rng(111)
+    h = rng.standard_normal(5)
+    phi = [[np.array([0.75, 0.25]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(5)]
+    phi[1][2] = np.array([0.0, 1.0])
+    phi[3][1] = np.array([1.0, 0.0])
+    gl = M.Glauber(M.Ising(J, h, 1.0), T, phi=phi)
+    bp = gl.mpbp(max_bond=16)
+    M.iterate(bp, maxiter=20, svd_trunc=M.TruncBondThresh(10), schedule="colored")
+    og = O.IndexedBiDiGraph(J != 0)
+    obp = O.mpbp(og, OF.glauber_factors(J != 0, J, h, 1.0, T), [2] * 5, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+
+
+def test_sirs_q3_tree_gpu():
+    """reference test/sirs_small_tree.jl (q = 3)."""
+    T = 2
+    A = np.array([[0, 1, 1], [1, 0, 0], [1, 0, 0]])
+    phi = [[np.array([0.5, 0.5, 0.0]) if t == 0 else np.ones(3) for t in range(T + 1)] for _ in range(3)]
+    phi[2][2] = np.array([0.0, 0.0, 1.0])
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SIRSFactor(0.4, 0.4, 0.3, 0.05)] * (T + 1)] * 3, 3, T, phi=phi, max_bond=27)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBond(27), schedule="colored")
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SIRSFactor(0.4, 0.4, 0.3, 0.05)] * (T + 1)] * 3, [3] * 3, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+
+
+def test_pair_observations_gpu():
+    """reference test/pair_observations.jl: time-dependent psi on the edges."""
+    T = 2
+    A = np.array([[0, 1, 1], [1, 0, 0], [1, 0, 0]])
+    g = M.IndexedBiDiGraph(A)
+    rng = np.random.default_rng(3)
+    psi = [None] * g.E
+    for (i, j, ij) in g.edges():
+        if i < j:
+            m = [rng.random((2, 2)) + 0.1 for _ in range(T + 1)]
+            psi[ij] = m
+            psi[int(g.rev[ij])] = [x.T.copy() for x in m]
+    phi = [[np.array([0.5, 0.5]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(3)]
+    bp = M.mpbp(g, [[M.SISFactor(0.5, 0.4, 0.1)] * (T + 1)] * 3, 2, T, phi=phi, psi=psi, max_bond=16)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBond(16), schedule="colored")
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(0.5, 0.4, 0.1)] * (T + 1)] * 3, [2] * 3, T, phi=phi, psi=psi)
+    p, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+    assert _rel(_flat(M.pair_beliefs(bp)[0]), _flat(exact_pair_marginals(obp, p))) < 1e-9
+
+
+def test_error_paths_do_not_abort():
+    A = np.array([[0, 1], [1, 0]])
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(0.5, 0.4)] * 3] * 2, 2, 2, max_bond=4)
+    with pytest.raises(M.MPBPError):
+        M.onebpiter(bp, [0], M.TruncBond(4), damp=1.5)      # reference asserts 0 <= damp < 1
+    with pytest.raises(M.MPBPError):
+        M.onebpiter(bp, [0, 0], M.TruncBond(4))
+    with pytest.raises(M.MPBPError):
+        M.onebpiter(bp, [7], M.TruncBond(4))
