@@ -372,6 +372,12 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
   }
   __syncthreads();
   if (n < 2) return 0;
+  // columns whose norm falls below 1e-14 ||A||_F are numerically null (they only carry the rounding noise
+  // of the preceding QR); rotating them against anything never converges and never matters
+  double fro2 = 0.0;
+  for (int idx = tid; idx < m * n; idx += WG_THREADS) { double v = A[(idx % m) + (long)lda * (idx / m)]; fro2 += v * v; }
+  fro2 = wg_sum(fro2, red);
+  const double nul = 1e-28 * fro2;
   const int ne = (n + 1) & ~1;          // even number of "players"
   const int npairs = ne / 2;
   const int sub = tid & 7;              // lane inside the 8-lane pair group
@@ -403,7 +409,7 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
               al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64);
             }
             const double lim = tol * sqrt(al * be);
-            if (fabs(ga) > lim && fabs(ga) > 1e-300) {
+            if (fabs(ga) > lim && al > nul && be > nul) {
               rotated = 1;
               const double zeta = (be - al) / (2.0 * ga);
               const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
