@@ -98,6 +98,8 @@ typedef struct {
   float ms_total;      /* device time of the call (HIP events on the context's stream) */
   float ms_orth;       /* time in the dominant kernel family (orthogonalisation sweeps of `op`) */
   int32_t n_orth_launches;
+  int64_t jacobi_sweeps; /* total one-sided Jacobi sweeps / calls of the call (diagnostics) */
+  int64_t jacobi_calls;
 } mpbp_stats;
 
 int mpbp_create(mpbp_ctx** out, const mpbp_desc* desc);
@@ -140,6 +142,7 @@ int mpbp_set_psi(mpbp_ctx* ctx, const double* psi);
  */
 int mpbp_set_messages(mpbp_ctx* ctx, const int32_t* bonds, const int64_t* offsets, const double* data);
 int mpbp_get_bonds(mpbp_ctx* ctx, int32_t* bonds /* [n_edges*(T+2)] */);
+/* offsets[e] < 0 skips edge e (partial download) */
 int mpbp_get_messages(mpbp_ctx* ctx, const int64_t* offsets, double* data);
 /* reset_messages!(bp) (src/mpbp.jl:72-80): uniform bond-1 messages */
 int mpbp_reset_messages(mpbp_ctx* ctx);
@@ -168,11 +171,15 @@ int mpbp_logz(mpbp_ctx* ctx, double* logz_node /* [n_nodes] */, double* logz_msg
 
 /* Enable/disable per-kernel HIP-event timing of the dominant kernel family (costs a sync per launch). */
 int mpbp_set_profiling(mpbp_ctx* ctx, int32_t on);
+/* Workgroup-seconds spent per engine phase since the last reset (profiling on), summed over workgroups;
+ * phases in the order of wg::PH_* (csrc/wg_blocks.h). */
+int mpbp_phase_profile(mpbp_ctx* ctx, double* seconds, int32_t n, int32_t reset);
 
 /* Self-test entry points used by tests/ (device building blocks against host references). */
 int mpbp_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, const double* A, const double* B,
                        double* C);
 int mpbp_selftest_qr(int32_t device, int32_t rows, int32_t cols, const double* A, double* R);
+int mpbp_selftest_qr_bench(int32_t device, int32_t rows, int32_t cols, int32_t nblocks, int32_t reps, double* ms_out);
 int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, const double* A, double* sigma,
                       double* V);
 

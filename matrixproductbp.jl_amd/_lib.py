@@ -41,13 +41,14 @@ class Layout(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("maxerr", C.c_double), ("n_compress", C.c_int64), ("nan_flag", C.c_int32),
                 ("capacity_flag", C.c_int32), ("jacobi_not_converged", C.c_int32), ("ms_total", C.c_float),
-                ("ms_orth", C.c_float), ("n_orth_launches", C.c_int32)]
+                ("ms_orth", C.c_float), ("n_orth_launches", C.c_int32), ("jacobi_sweeps", C.c_int64),
+                ("jacobi_calls", C.c_int64)]
 
 
 EXPORTS = ["mpbp_create", "mpbp_destroy", "mpbp_last_error", "mpbp_slab_layout", "mpbp_slab_pointers",
            "mpbp_set_factor", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
            "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_pair_beliefs",
-           "mpbp_free_energy", "mpbp_logz", "mpbp_set_profiling", "mpbp_selftest_gemm", "mpbp_selftest_qr",
+           "mpbp_free_energy", "mpbp_logz", "mpbp_set_profiling", "mpbp_phase_profile", "mpbp_selftest_gemm", "mpbp_selftest_qr", "mpbp_selftest_qr_bench",
            "mpbp_selftest_svd"]
 
 
@@ -103,8 +104,10 @@ def lib():
     L.mpbp_free_energy.argtypes = [C.c_void_p, dp]
     L.mpbp_logz.argtypes = [C.c_void_p, dp, dp]
     L.mpbp_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    L.mpbp_phase_profile.argtypes = [C.c_void_p, dp, C.c_int32, C.c_int32]
     L.mpbp_selftest_gemm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
     L.mpbp_selftest_qr.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp]
+    L.mpbp_selftest_qr_bench.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp]
     L.mpbp_selftest_svd.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
     _lib = L
     return L

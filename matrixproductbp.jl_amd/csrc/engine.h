@@ -38,12 +38,14 @@ struct EngCfg {
   // LDS layout (offsets in doubles from the dynamic LDS base); negative => use the global copy
   int32_t lds_gemm, lds_qr, lds_misc, lds_A1c, lds_A2c, lds_E, lds_JA, lds_JV, lds_rdim;
   mpbp_trunc trunc;
+  wg::Prof* prof;     // optional phase timers (null = off)
 };
 
 struct EngStats {
   unsigned long long maxerr_bits;
   unsigned long long n_compress;
   int32_t nan_flag, capacity_flag, jacobi_fail;
+  unsigned long long jac_sweeps, jac_calls;
 };
 
 namespace eng {
@@ -51,6 +53,7 @@ namespace eng {
 using namespace wg;
 
 __device__ __forceinline__ int r16(int x) { return (x + 15) & ~15; }
+__device__ __forceinline__ int r32(int x) { return (x + 31) & ~31; }
 
 // stage logical core t of a train into dst[m + a*(n + an*(y + ny*xi))]
 __device__ inline void stage_core(double* dst, const double* base, const int32_t* bond, int64_t stride, int L,
@@ -117,6 +120,9 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
   auto LB1 = [&](int t) { return mirror ? P.bond1[L - t] : P.bond1[t]; };
   auto LB2 = [&](int t) { return mirror ? P.bond2[L - t] : P.bond2[t]; };
   auto TP = [&](int t) { return mirror ? (L - 1 - t) : t; };
+  Prof* pr = cfg.prof;
+  unsigned long long plast = pr ? wall_clock64() : 0ULL;
+#define PROF(ph) prof_mark(pr, plast, ph)
 
   // ------------------------------------------------------------------ sweep 1: triangular factors
   if (tid == 0) { rdim[L] = 1; LfS[(int64_t)L * cfg.lf_stride] = 1.0; }
@@ -131,16 +137,18 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     __syncthreads();
     build_E(E, A2c, P.pyy + (int64_t)TP(t) * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
     __syncthreads();
+    PROF(PH_STAGE);
     // Y1: Z[(m1,y1,xi) ; (n2,k)] = sum_n1 A1[m1,n1,y1,xi] Lf1[(n1,n2),k]
     const int M1 = a * ny1 * q;
     gemm(M1, bn * r1, an, A1c,
          [=](int i) { return (i % a) + a * an * (i / a); }, [=](int kk) { return a * kk; },
          Lf1, [=](int kk) { return kk; }, [=](int j) { return (int64_t)an * j; }, true,
          Z, [=](int i) { return i; }, [=](int j) { return (int64_t)M1 * j; }, false, ldsG);
+    PROF(PH_Y1);
     // Y2 (per xi): Y[(k,y,xi) ; (m1,m2)] = sum_(n2,y1) E_xi[(m2,y),(n2,y1)] Z[(m1,y1,xi),(n2,k)]
     const int rowsY = r1 * ny * q;
-    const int ldY = r16(rowsY);
-    const int cols16 = r16(Bm);
+    const int ldY = r32(rowsY);
+    const int cols16 = r16(Bm) + 16;
     // zero padding rows / columns
     for (int64_t idx = tid; idx < (int64_t)(ldY - rowsY) * cols16; idx += WG_THREADS) {
       int rr = rowsY + (int)(idx % (ldY - rowsY)); int64_t c = idx / (ldY - rowsY);
@@ -158,7 +166,8 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
            [=](int i) { return (int64_t)r1 * (i / b) + (int64_t)ldY * a * (i % b); },
            [=](int j) { return (int64_t)(j / a) + (int64_t)ldY * (j % a); }, false, ldsG);
     }
-    qr_r(Y, ldY, rowsY, Bm, ldsQ);
+    PROF(PH_Y2);
+    qr_r(Y, ldY, rowsY, Bm, ldsQ, ldsG, pr, &plast, PH_QR1_PANEL, PH_QR1_TRAIL);
     const int kmax = min(rowsY, Bm);
     // scale = max |R| over the upper trapezoid
     double mx = 0.0;
@@ -175,6 +184,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     }
     if (tid == 0) rdim[t] = kmax;
     __syncthreads();
+    PROF(PH_LF);
   }
 
   // ------------------------------------------------------------------ sweep 2: truncation
@@ -192,6 +202,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     __syncthreads();
     build_E(E, A2c, P.pyy + (int64_t)tp * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
     __syncthreads();
+    PROF(PH_STAGE);
     // N1: T1[(n1,y1,xi) ; (k,m2)] = sum_m1 A1[m1,n1,y1,xi] C[k,(m1,m2)]
     const int MT1 = an * ny1 * q;
     gemm(MT1, kc * b, a, A1c,
@@ -223,6 +234,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
       }
       __syncthreads();
     }
+    PROF(PH_N);
     double* oc = P.out + (int64_t)tp * P.ostride;
     if (t == L - 1) {
       // last core: [kc, 1, s] = Nt[(k,s), 0]
@@ -237,8 +249,8 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     const int r1 = rdim[t + 1];
     const double* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;
     // Mt^T [r1 x Rr] = Lf1^T Nt^T
-    const int ldM = r16(r1);
-    const int Rr16 = r16(Rr);
+    const int ldM = r32(r1);
+    const int Rr16 = r16(Rr) + 16;
     for (int64_t idx = tid; idx < (int64_t)(ldM - r1) * Rr16; idx += WG_THREADS) {
       int rr = r1 + (int)(idx % (ldM - r1)); int64_t c = idx / (ldM - r1);
       Mt[rr + (int64_t)ldM * c] = 0.0;
@@ -247,27 +259,47 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     gemm(r1, Rr, Bn, Lf1, [=](int i) { return (int64_t)Bn * i; }, [=](int kk) { return kk; },
          Nt, [=](int kk) { return (int64_t)Rr * kk; }, [=](int j) { return j; }, false,
          Mt, [=](int i) { return i; }, [=](int j) { return (int64_t)ldM * j; }, false, ldsG);
-    qr_r(Mt, ldM, r1, Rr, ldsQ);
+    PROF(PH_MT);
+    qr_r(Mt, ldM, r1, Rr, ldsQ, ldsG, pr, &plast, PH_QR2_PANEL, PH_QR2_TRAIL);
     const int k2 = min(r1, Rr);
-    // JA [k2 x Rr] = upper trapezoid of R2
+    // Left singular vectors of M_t = right singular vectors of R2.  Hestenes on the columns of
+    // JA = R2^T [Rr x k2] (the "L form": about half the sweeps of the R form) WITHOUT accumulating V:
+    // the rotated columns are sigma_j u_j.  Columns below 1e-14 ||.||_F are numerically null (they only
+    // multiply what the right environment annihilates) and become zero columns of U.
+    const int ldJ = Rr | 1;
+    double fro2 = 0.0;
     for (int idx = tid; idx < k2 * Rr; idx += WG_THREADS) {
-      int r = idx % k2, c = idx / k2;
-      JA[idx] = (c >= r) ? Mt[r + (int64_t)ldM * c] : 0.0;
+      int r = idx % Rr, c = idx / Rr;            // JA[r, c] = R2[c, r]
+      double v = (r >= c) ? Mt[c + (int64_t)ldM * r] : 0.0;
+      JA[r + ldJ * c] = v;
+      fro2 += v * v;
     }
+    fro2 = wg_sum(fro2, red);
     __syncthreads();
-    int sw = jacobi_rsv(JA, k2, k2, Rr, JV, Rr, red, 60);
-    if (sw < 0 && tid == 0) stats->jacobi_fail = 1;
-    // singular values = column norms; order descending
-    for (int c = tid; c < Rr; c += WG_THREADS) {
+    int sw = jacobi_rsv(JA, ldJ, Rr, k2, nullptr, 0, red, 60);
+    if (tid == 0) {
+      if (sw < 0) stats->jacobi_fail = 1;
+      atomicAdd(&stats->jac_sweeps, (unsigned long long)(sw < 0 ? 60 : sw));
+      atomicAdd(&stats->jac_calls, 1ULL);
+    }
+    PROF(PH_JAC);
+    // singular values = column norms; normalise the columns (null ones -> 0); order descending
+    const double nul2 = 1e-28 * fro2;
+    for (int c = tid; c < Rr; c += WG_THREADS) sig[c] = 0.0;
+    __syncthreads();
+    for (int c = tid; c < k2; c += WG_THREADS) {
       double s = 0.0;
-      for (int r = 0; r < k2; r++) { double v = JA[r + k2 * c]; s += v * v; }
-      sig[c] = sqrt(s);
+      for (int r = 0; r < Rr; r++) { double v = JA[r + ldJ * c]; s += v * v; }
+      const bool ok = s > nul2 && s > 0.0;
+      const double sg = ok ? sqrt(s) : 0.0, inv = ok ? 1.0 / sqrt(s) : 0.0;
+      for (int r = 0; r < Rr; r++) JA[r + ldJ * c] *= inv;
+      sig[c] = sg;
     }
     __syncthreads();
-    for (int c = tid; c < Rr; c += WG_THREADS) {
+    for (int c = tid; c < k2; c += WG_THREADS) {
       const double sc = sig[c];
       int rank = 0;
-      for (int j = 0; j < Rr; j++) { double sj = sig[j]; rank += (sj > sc) || (sj == sc && j < c); }
+      for (int j = 0; j < k2; j++) { double sj = sig[j]; rank += (sj > sc) || (sj == sc && j < c); }
       ord[rank] = c;
     }
     __syncthreads();
@@ -300,19 +332,21 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     for (int idx = tid; idx < Rr * kp; idx += WG_THREADS) {
       int row = idx % Rr, k2i = idx / Rr;
       int k = row % kc, s = row / kc;
-      double v = JV[row + Rr * ord[k2i]];
+      double v = JA[row + ldJ * ord[k2i]];
       // physical layout: !mirror [kc, kp, s];  mirror [kp, kc, s]
       int64_t off = mirror ? ((int64_t)k2i + (int64_t)kp * (k + (int64_t)kc * s))
                            : ((int64_t)k + (int64_t)kc * (k2i + (int64_t)kp * s));
       oc[off] = v;
     }
     if (tid == 0) P.obond[mirror ? (L - (t + 1)) : (t + 1)] = kp;
+    PROF(PH_TRUNC);
     // carry C' [kp x Bn] = U^T Nt
-    gemm(kp, Bn, Rr, JV, [=](int i) { return (int64_t)Rr * ord[i]; }, [=](int kk) { return kk; },
+    gemm(kp, Bn, Rr, JA, [=](int i) { return (int64_t)ldJ * ord[i]; }, [=](int kk) { return kk; },
          Nt, [=](int kk) { return kk; }, [=](int j) { return (int64_t)Rr * j; }, true,
          Cnew, [=](int i) { return i; }, [=](int j) { return (int64_t)kp * j; }, false, ldsG);
     double* tmp = Ccur; Ccur = Cnew; Cnew = tmp;
     kc = kp;
+    PROF(PH_CARRY);
   }
 
   // ------------------------------------------------------------------ normalize_eachmatrix! + z
@@ -330,6 +364,8 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
       logz -= log(mx);
     }
   }
+  PROF(PH_NORM);
+#undef PROF
   if (tid == 0) {
     *P.ologz = logz;
     atomicAdd(&stats->n_compress, 1ULL);

@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(WG_THREADS) st_gemm_kernel(int M, int N, int K
 }
 __global__ void __launch_bounds__(WG_THREADS) st_qr_kernel(double* Y, int ld, int rows, int cols) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  wg::qr_r(Y, ld, rows, cols, lds);
+  wg::qr_r(Y + (int64_t)blockIdx.x * ld * (((cols + 15) & ~15) + 16), ld, rows, cols, lds, lds + wg::QR_LDS_DOUBLES);
 }
 __global__ void __launch_bounds__(WG_THREADS) st_svd_kernel(double* A, int m, int n, double* V, double* sigma, int* sweeps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];

@@ -68,7 +68,7 @@ struct mpbp_ctx {
   double* d_logz_node = nullptr;  // [N]
   double* d_logz_pos = nullptr;   // [nnz]  log z_{i->j} per neighbour position
   std::vector<double> h_logz_node, h_logz_pos, h_f;
-  EngStats* d_stats = nullptr; int* d_counter = nullptr;
+  EngStats* d_stats = nullptr; int* d_counter = nullptr; wg::Prof* d_prof = nullptr;
   double* d_one = nullptr; int32_t* d_ones = nullptr; double* d_ident = nullptr; int ident_n = 0;
   // tables
   bool tables_dirty = true;
@@ -140,6 +140,8 @@ extern "C" int mpbp_create(mpbp_ctx** out, const mpbp_desc* d) {
   if ((e = hipMalloc(&c->d_logz_pos, sizeof(double) * nnz)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&c->d_stats, sizeof(EngStats))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&c->d_counter, sizeof(int) * 64)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_prof, sizeof(wg::Prof))) != hipSuccess) return bail("hipMalloc", e);
+  hipMemset(c->d_prof, 0, sizeof(wg::Prof));
   if ((e = hipMalloc(&c->d_one, sizeof(double) * 4)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&c->d_ones, sizeof(int32_t) * (c->L + 2))) != hipSuccess) return bail("hipMalloc", e);
   c->ident_n = c->q * c->q;
@@ -171,7 +173,7 @@ extern "C" void mpbp_destroy(mpbp_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_cores && c->d_cores) hipFree(c->d_cores);
   if (c->own_bonds && c->d_bonds) hipFree(c->d_bonds);
-  for (void* p : {(void*)c->d_beliefs, (void*)c->d_logz_node, (void*)c->d_logz_pos, (void*)c->d_stats, (void*)c->d_counter,
+  for (void* p : {(void*)c->d_beliefs, (void*)c->d_logz_node, (void*)c->d_logz_pos, (void*)c->d_stats, (void*)c->d_counter, (void*)c->d_prof,
                   (void*)c->d_one, (void*)c->d_ones, (void*)c->d_ident, (void*)c->d_tab, (void*)c->arena.base, (void*)c->scratch.base})
     if (p) hipFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -190,6 +192,15 @@ extern "C" int mpbp_slab_pointers(const mpbp_ctx* c, void** cores, void** bonds)
   return MPBP_OK;
 }
 extern "C" int mpbp_set_profiling(mpbp_ctx* c, int32_t on) { if (!c) return MPBP_EINVAL; c->profiling = on != 0; return MPBP_OK; }
+extern "C" int mpbp_phase_profile(mpbp_ctx* c, double* seconds, int32_t n, int32_t reset) {
+  if (!c || !seconds) return MPBP_EINVAL;
+  hipSetDevice(c->device);
+  wg::Prof h;
+  HIPCHK(c, hipMemcpy(&h, c->d_prof, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n && i < 24; i++) seconds[i] = (double)h.t[i] * 1e-8;   // wall_clock64 ticks at 100 MHz
+  if (reset) HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(wg::Prof)));
+  return MPBP_OK;
+}
 
 // ================================================================================================
 // inputs
@@ -268,6 +279,7 @@ extern "C" int mpbp_get_messages(mpbp_ctx* c, const int64_t* offsets, double* da
   std::vector<double> slot((size_t)c->slot_doubles);
   std::vector<int32_t> b(L + 1);
   for (int e = 0; e < c->E; e++) {
+    if (offsets[e] < 0) continue;      // negative offset: skip this edge (partial download)
     HIPCHK(c, hipMemcpy(slot.data(), c->slot_cores(e), sizeof(double) * c->slot_doubles, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(b.data(), c->slot_bonds(e), sizeof(int32_t) * (L + 1), hipMemcpyDeviceToHost));
     double* dst = data + offsets[e];
@@ -438,14 +450,14 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   cfg.lf_stride = (Bmax * Bmax + 15) & ~int64_t(15);
   cfg.off_Lf = take(cfg.lf_stride * (L + 1));
   cfg.off_Z = take((int64_t)pl.cap1 * pl.ny1 * pl.q * pl.cap2 * Bmax);
-  cfg.off_Y = take((int64_t)r16h((int)(Bmax * pl.ny * pl.q)) * r16h((int)Bmax));
+  cfg.off_Y = take((int64_t)(r16h((int)(Bmax * pl.ny * pl.q)) + 32) * (r16h((int)Bmax) + 16));
   cfg.off_C0 = take((int64_t)pl.capout * Bmax);
   cfg.off_C1 = take((int64_t)pl.capout * Bmax);
   cfg.off_T1 = take((int64_t)pl.cap1 * pl.ny1 * pl.q * pl.capout * pl.cap2);
   cfg.off_Nt = take((int64_t)nmax * Bmax);
-  cfg.off_Mt = take((int64_t)r16h((int)Bmax) * r16h(nmax));
-  cfg.off_JA = take((int64_t)nmax * nmax);
-  cfg.off_JV = take((int64_t)nmax * nmax);
+  cfg.off_Mt = take((int64_t)(r16h((int)Bmax) + 32) * (r16h(nmax) + 16));
+  cfg.off_JA = take((int64_t)(nmax + 1) * nmax);
+  cfg.off_JV = take(16);
   const int64_t nA1 = (int64_t)pl.cap1 * pl.cap1 * pl.ny1 * pl.q, nA2 = (int64_t)pl.cap2 * pl.cap2 * pl.ny2 * pl.q;
   const int64_t nE = (int64_t)pl.q * pl.cap2 * pl.ny * pl.cap2 * pl.ny1;
   cfg.off_A1c = take(nA1); cfg.off_A2c = take(nA2); cfg.off_E = take(nE);
@@ -460,11 +472,11 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   const int64_t budget = (150 * 1024) / 8;
   const int64_t base = l;
   const int64_t coresE = ((nA1 + 3) & ~3) + ((nA2 + 3) & ~3) + ((nE + 3) & ~3);
-  const int64_t jac = 2 * (((int64_t)nmax * nmax + 3) & ~3);
+  const int64_t jac = (((int64_t)(nmax + 1) * nmax + 3) & ~3);     // JA only (V is not accumulated)
   bool cores_fit = base + coresE <= budget, jac_fit = base + jac <= budget;
   if (cores_fit) { int64_t o = base; cfg.lds_A1c = (int32_t)o; o += (nA1 + 3) & ~3; cfg.lds_A2c = (int32_t)o; o += (nA2 + 3) & ~3; cfg.lds_E = (int32_t)o; }
   else { cfg.lds_A1c = cfg.lds_A2c = cfg.lds_E = -1; }
-  if (jac_fit) { cfg.lds_JA = (int32_t)base; cfg.lds_JV = (int32_t)(base + (((int64_t)nmax * nmax + 3) & ~3)); }
+  if (jac_fit) { cfg.lds_JA = (int32_t)base; cfg.lds_JV = -1; }
   else { cfg.lds_JA = cfg.lds_JV = -1; }
   int64_t top = base + std::max(cores_fit ? coresE : 0, jac_fit ? jac : 0);
   lds_bytes = (size_t)top * 8;
@@ -483,6 +495,7 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   for (int i = 0; i < nprob; i++) sorted[i] = pl.probs[idx[i]];
   EngCfg cfg; size_t lds_bytes;
   plan_cfg(pl, c->L, trunc, cfg, lds_bytes);
+  cfg.prof = (c->profiling && count_as_orth) ? c->d_prof : nullptr;
   HIPCHK(c, hipFuncSetAttribute((const void*)eng_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   int per_cu = 1;
   hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, eng_kernel, WG_THREADS, lds_bytes);
@@ -778,7 +791,7 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
   mpbp_stats st{};
   { double v; unsigned long long b = hs.maxerr_bits; memcpy(&v, &b, 8); st.maxerr = v; }
   st.n_compress = (int64_t)hs.n_compress; st.nan_flag = hs.nan_flag; st.capacity_flag = hs.capacity_flag;
-  st.jacobi_not_converged = hs.jacobi_fail; st.ms_total = ms; st.ms_orth = ms_orth; st.n_orth_launches = n_orth;
+  st.jacobi_not_converged = hs.jacobi_fail; st.jacobi_sweeps = (int64_t)hs.jac_sweeps; st.jacobi_calls = (int64_t)hs.jac_calls; st.ms_total = ms; st.ms_orth = ms_orth; st.n_orth_launches = n_orth;
   c->last = st;
   if (stats) *stats = st;
   if (hs.capacity_flag) return c->fail(MPBP_ECAPACITY, "a truncated bond exceeded max_bond=%d; results were clamped", cap);
@@ -868,18 +881,46 @@ extern "C" int mpbp_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t 
 
 extern "C" int mpbp_selftest_qr(int32_t device, int32_t rows, int32_t cols, const double* A, double* R) {
   STCHK(hipSetDevice(device));
-  const int ld = (rows + 15) & ~15, c16 = (cols + 15) & ~15;
+  const int ld = (rows + 31) & ~31, c16 = ((cols + 15) & ~15) + 16;
   std::vector<double> Y((size_t)ld * c16, 0.0);
   for (int j = 0; j < cols; j++) for (int i = 0; i < rows; i++) Y[i + (size_t)ld * j] = A[i + (size_t)rows * j];
   double* dY;
   STCHK(hipMalloc(&dY, sizeof(double) * Y.size()));
   STCHK(hipMemcpy(dY, Y.data(), sizeof(double) * Y.size(), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), wg::QR_LDS_DOUBLES * 8, 0, dY, ld, rows, cols);
+  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 256) * 8, 0, dY, ld, rows, cols);
   STCHK(hipGetLastError()); STCHK(hipDeviceSynchronize());
   STCHK(hipMemcpy(Y.data(), dY, sizeof(double) * Y.size(), hipMemcpyDeviceToHost));
   const int k = std::min(rows, cols);
   for (int j = 0; j < cols; j++) for (int i = 0; i < k; i++) R[i + (size_t)k * j] = (j >= i) ? Y[i + (size_t)ld * j] : 0.0;
   hipFree(dY);
+  return MPBP_OK;
+}
+
+// times `reps` launches of nblocks concurrent QRs (each block its own random matrix); returns ms per launch
+extern "C" int mpbp_selftest_qr_bench(int32_t device, int32_t rows, int32_t cols, int32_t nblocks, int32_t reps, double* ms_out) {
+  STCHK(hipSetDevice(device));
+  const int ld = (rows + 31) & ~31, c16 = ((cols + 15) & ~15) + 16;
+  const size_t per = (size_t)ld * c16;
+  std::vector<double> Y(per, 0.0);
+  unsigned long long st = 88172645463325252ULL;
+  for (int j = 0; j < cols; j++) for (int i = 0; i < rows; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; Y[i + (size_t)ld * j] = (double)(st % 2000001) / 1e6 - 1.0; }
+  double* dY; double* dY0;
+  STCHK(hipMalloc(&dY, sizeof(double) * per * nblocks)); STCHK(hipMalloc(&dY0, sizeof(double) * per));
+  STCHK(hipMemcpy(dY0, Y.data(), sizeof(double) * per, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float tot = 0.f;
+  for (int r = 0; r < reps + 1; r++) {
+    for (int b = 0; b < nblocks; b++) STCHK(hipMemcpyAsync(dY + per * b, dY0, sizeof(double) * per, hipMemcpyDeviceToDevice, 0));
+    STCHK(hipDeviceSynchronize());
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(st_qr_kernel, dim3(nblocks), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 256) * 8, 0, dY, ld, rows, cols);
+    hipEventRecord(e1, 0);
+    STCHK(hipEventSynchronize(e1));
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0) tot += ms;
+  }
+  *ms_out = tot / reps;
+  hipFree(dY); hipFree(dY0); hipEventDestroy(e0); hipEventDestroy(e1);
   return MPBP_OK;
 }
 

@@ -24,6 +24,18 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 namespace wg {
 
+// optional phase profile: lane 0 of the workgroup adds elapsed wall-clock ticks (100 MHz) per phase
+struct Prof { unsigned long long t[24]; };
+__device__ __forceinline__ void prof_mark(Prof* pr, unsigned long long& last, int phase) {
+  if (pr && threadIdx.x == 0) {
+    unsigned long long now = wall_clock64();
+    atomicAdd(&pr->t[phase], now - last);
+    last = now;
+  }
+}
+enum { PH_STAGE = 0, PH_Y1, PH_Y2, PH_QR1_PANEL, PH_QR1_TRAIL, PH_LF, PH_N, PH_MT, PH_QR2_PANEL, PH_QR2_TRAIL,
+       PH_JAC, PH_TRUNC, PH_CARRY, PH_NORM, PH_COUNT };
+
 constexpr int GM_MB = 96;    // rows per M block (6 MFMA row tiles)
 constexpr int GM_NT = 128;   // columns per N chunk (one 16-col tile per wave)
 constexpr int GM_KC = 16;    // K per LDS chunk
@@ -203,172 +215,399 @@ __device__ inline double wg_maxabs(const double* A, long ld, int rows, int cols,
 
 // ---------------------------------------------------------------------------------------------
 // Blocked Householder QR, R only, in place.
-//   Y: column-major, leading dim ld (multiple of 16, >= rows rounded up to 16); the padding rows
-//      [rows, ld16) and padding columns [cols, cols16) MUST be zero on entry (cols16 = cols up to 16).
+//   Y: column-major, leading dim ld (multiple of 32, >= rows rounded up to 32); the padding rows
+//      [rows, rows32) and the padding columns [cols, cols16 + 16) MUST exist and be zero on entry
+//      (cols16 = cols rounded up to 16; the extra 16 columns absorb tiles that start unaligned after a
+//      short last panel).
 //   On exit the upper trapezoid Y[0:min(rows,cols), 0:cols] holds R (everything below is garbage).
 //   lds: QR_LDS_DOUBLES doubles.
-// Panel factorisation is LAPACK dgeqr2/dlarft (level 2, in global memory, workgroup reductions);
-// the trailing update C -= V (T^T (V^T C)) runs per 16-column tile inside one wave, entirely in MFMA
-// registers: W0 = V^T C (k-permuted 32-B row fragments, full 128-B lines), W = T^T W0 (accumulator
-// fed back as B operand), C^T -= W^T V^T (so that every C access is a full line).
+// Panel (16 columns): LAPACK dgeqr2 + dlarft.  Fast path: the panel lives in registers (4 rows per
+// thread, rows <= 2048 below the diagonal block) and each column costs ONE workgroup reduction of 16
+// values (|x|^2 and the 15 dot products, taken before scaling); generic path: level 2 in global memory.
+// Trailing update C -= V (T^T (V^T C)) per 16-column tile inside one wave, entirely in MFMA registers:
+// W0 = V^T C (k-permuted 32-B row fragments = full 128-B lines), W = T^T W0 (accumulator fed back as
+// B operand), C^T -= W^T V^T (so that every C access is a full line); global loads are issued four row
+// blocks ahead of the MFMAs that consume them.
 // ---------------------------------------------------------------------------------------------
 constexpr int QR_NB = 16;
-constexpr int QR_LDS_DOUBLES = WG_WAVES * 16 + 16 * 16 + 16 + 32;
+constexpr int QR_RS = 4;      // rows per thread of the register panel
+constexpr int QR_TC = 4;      // column tiles a wave updates together
+constexpr int QR_LDS_DOUBLES = WG_WAVES * 16 + 16 * 16 + 16 + 2 * 32 + 2 * 16;
 
-__device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds) {
+// 16 per-lane partial values -> lanes with (lane & 3) == 0 hold the wave total of value
+// idx = ((lane>>5)&1)<<3 | ((lane>>4)&1)<<2 | ((lane>>3)&1)<<1 | ((lane>>2)&1)   (17 shuffles instead of 96)
+__device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane, int& idx) {
+  double a8[8], a4[4], a2[2], a1;
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double keep = b5 ? v[i + 8] : v[i], send = b5 ? v[i] : v[i + 8];
+    a8[i] = keep + __shfl_xor(send, 32, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double keep = b4 ? a8[i + 4] : a8[i], send = b4 ? a8[i] : a8[i + 4];
+    a4[i] = keep + __shfl_xor(send, 16, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    double keep = b3 ? a4[i + 2] : a4[i], send = b3 ? a4[i] : a4[i + 2];
+    a2[i] = keep + __shfl_xor(send, 8, 64);
+  }
+  {
+    double keep = b2 ? a2[1] : a2[0], send = b2 ? a2[0] : a2[1];
+    a1 = keep + __shfl_xor(send, 4, 64);
+  }
+  a1 += __shfl_xor(a1, 2, 64);
+  a1 += __shfl_xor(a1, 1, 64);
+  idx = (b5 ? 8 : 0) | (b4 ? 4 : 0) | (b3 ? 2 : 0) | (b2 ? 1 : 0);
+  return a1;
+}
+
+// register-resident panel factorisation (rows - j0 <= QR_RS * WG_THREADS).  The active column is always
+// register column 0 (finished columns are stored and the register panel is shifted), so every register
+// index is a compile-time constant.  T is NOT built here (see qr_build_T).
+__device__ __attribute__((noinline)) void qr_panel_regs(double* Y, long ld, int rows, int j0, int nb, double* red,
+                                              double* tau, double* bc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double P[QR_RS][QR_NB];
+  bool rv[QR_RS];
+#pragma unroll
+  for (int s = 0; s < QR_RS; s++) {
+    const int r = j0 + tid + WG_THREADS * s;
+    rv[s] = r < rows;
+#pragma unroll
+    for (int c = 0; c < QR_NB; c++) P[s][c] = (rv[s] && c < nb) ? Y[(long)(j0 + c) * ld + r] : 0.0;
+  }
+  double* tot = bc;            // [2][16] wave-summed totals (double buffered by column parity)
+  double* rowb = bc + 32;      // [2][16] the pivot row of the panel
+  for (int jj = 0; jj < nb; jj++) {
+    double* totj = tot + 16 * (jj & 1);
+    double* rowj = rowb + 16 * (jj & 1);
+    // partial |x|^2 (c = 0) and dots with the remaining columns over the rows strictly below the pivot row
+    double vals[16];
+#pragma unroll
+    for (int c = 0; c < QR_NB; c++) vals[c] = 0.0;
+#pragma unroll
+    for (int s = 0; s < QR_RS; s++) {
+      const bool below = rv[s] && (s > 0 || tid > jj);
+      const double x = below ? P[s][0] : 0.0;
+#pragma unroll
+      for (int c = 0; c < QR_NB; c++) vals[c] += x * P[s][c];
+    }
+    int idx;
+    const double wsum = wave_sum16(vals, lane, idx);
+    if ((lane & 3) == 0) red[wave * 16 + idx] = wsum;
+    if (tid == jj) {
+#pragma unroll
+      for (int c = 0; c < QR_NB; c++) rowj[c] = P[0][c];
+    }
+    __syncthreads();
+    if (tid < 16) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int w = 0; w < WG_WAVES; w++) sacc += red[w * 16 + tid];
+      totj[tid] = sacc;
+    }
+    __syncthreads();
+    const double ss = totj[0];
+    const double alpha = rowj[0];
+    double beta, tj, scale;
+    if (ss == 0.0) { beta = alpha; tj = 0.0; scale = 0.0; }
+    else {
+      beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+      tj = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    if (tid == 0) tau[jj] = tj;
+    // update the registers: w_c = row term + scale * dot
+#pragma unroll
+    for (int s = 0; s < QR_RS; s++) {
+      const bool below = rv[s] && (s > 0 || tid > jj);
+      const bool pivot = (s == 0) && (tid == jj);
+      const double v = below ? P[s][0] * scale : (pivot ? 1.0 : 0.0);
+      if (below) P[s][0] = v;
+      if (pivot) P[s][0] = beta;
+#pragma unroll
+      for (int c = 1; c < QR_NB; c++) P[s][c] -= (tj * (rowj[c] + scale * totj[c])) * v;
+    }
+    // store the finished column and shift the register panel
+    const long coff = (long)(j0 + jj) * ld;
+#pragma unroll
+    for (int s = 0; s < QR_RS; s++) {
+      if (rv[s]) Y[coff + j0 + tid + WG_THREADS * s] = P[s][0];
+#pragma unroll
+      for (int c = 0; c < QR_NB - 1; c++) P[s][c] = P[s][c + 1];
+      P[s][QR_NB - 1] = 0.0;
+    }
+  }
+  __syncthreads();
+}
+
+// T of the block reflector from the Gram matrix of V (dlarft recurrence with z = G(0:j, j)):
+//   G = V^T V by MFMA (every wave takes the row blocks rb = wave, wave+8, ...), reduced through `big`
+//   (>= WG_WAVES*256 doubles of LDS), then T(0:j,j) = -tau_j T(0:j,0:j) G(0:j,j), T(j,j) = tau_j.
+__device__ __forceinline__ void qr_build_T(const double* Y, long ld, int rows16, int j0, int nb, double* Ts,
+                                           const double* tau, double* big) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nrb = (rows16 - j0) >> 4;
+  const double* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  d4 acc = d4{0, 0, 0, 0};
+  for (int rb = wave; rb < nrb; rb += WG_WAVES) {
+    d4 v = *reinterpret_cast<const d4*>(vcol + 16 * rb);
+    if (rb == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int rho = 4 * g + e;
+        v[e] = (rho > l15) ? v[e] : ((rho == l15) ? 1.0 : 0.0);
+      }
+    }
+    if (l15 >= nb) v = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc = mfma(v[e], v[e], acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) big[wave * 256 + (g + 4 * r) + 16 * l15] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int w = 0; w < WG_WAVES; w++) sacc += big[w * 256 + tid];
+    big[tid] = sacc;        // G[i + 16 j]   (safe: every thread reads column `tid` of all waves first)
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; j++) {
+    const double tj = tau[j];
+    if (tid < j) {
+      double sacc = 0.0;
+      for (int i2 = tid; i2 < j; i2++) sacc += Ts[tid + 16 * i2] * big[i2 + 16 * j];
+      Ts[tid + 16 * j] = -tj * sacc;
+    }
+    if (tid == 0) Ts[j + 16 * j] = tj;
+    __syncthreads();
+  }
+}
+
+// generic panel factorisation, panel in global memory (any number of rows)
+__device__ __attribute__((noinline)) void qr_panel_global(double* Y, long ld, int rows, int j0, int nb, double* red, double* Ts,
+                                       double* tau, double* bc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int jj = 0; jj < nb; jj++) {
+    const int col = j0 + jj;
+    double* x = Y + (long)col * ld;
+    double ss = 0.0;
+    for (int r = col + 1 + tid; r < rows; r += WG_THREADS) { double v = x[r]; ss += v * v; }
+    ss = wg_sum(ss, red);
+    const double alpha = x[col];
+    double beta, tj, scale;
+    if (ss == 0.0) { beta = alpha; tj = 0.0; scale = 0.0; }
+    else {
+      beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+      tj = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    __syncthreads();   // everyone has read alpha
+    for (int r = col + 1 + tid; r < rows; r += WG_THREADS) x[r] *= scale;
+    if (tid == 0) { x[col] = beta; tau[jj] = tj; }
+    __syncthreads();
+    double part[QR_NB];
+#pragma unroll
+    for (int c = 0; c < QR_NB; c++) part[c] = 0.0;
+    for (int r = col + 1 + tid; r < rows; r += WG_THREADS) {
+      const double v = x[r];
+#pragma unroll
+      for (int c = 0; c < QR_NB; c++)
+        if (c != jj && c < nb) part[c] += v * Y[(long)(j0 + c) * ld + r];
+    }
+#pragma unroll
+    for (int c = 0; c < QR_NB; c++) part[c] = wave_sum(part[c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < QR_NB; c++) red[wave * 16 + c] = part[c];
+    }
+    __syncthreads();
+    if (tid < 16) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < WG_WAVES; w++) s += red[w * 16 + tid];
+      if (tid < nb && tid != jj) s += Y[(long)(j0 + tid) * ld + col];
+      bc[tid] = s;
+    }
+    __syncthreads();
+    for (int r = col + 1 + tid; r < rows; r += WG_THREADS) {
+      const double v = x[r];
+      for (int c = jj + 1; c < nb; c++) Y[(long)(j0 + c) * ld + r] -= tj * bc[c] * v;
+    }
+    if (tid > jj && tid < nb) Y[(long)(j0 + tid) * ld + col] -= tj * bc[tid];
+    if (tid < jj) {
+      double s = 0.0;
+      for (int i2 = tid; i2 < jj; i2++) s += Ts[tid + 16 * i2] * bc[i2];
+      Ts[tid + 16 * jj] = -tj * s;
+    }
+    if (tid == 0) Ts[jj + 16 * jj] = tj;
+    __syncthreads();
+  }
+}
+
+// Trailing update of NT adjacent 16-column tiles (first column cb0) by one wave - branch free, so that the
+// compiler keeps the global loads in flight behind counted vmcnt waits (any predicated load becomes a branch
+// and a vmcnt(0)).  Requires: ld % 32 == 0, rows padded with zeros up to rows32, and the buffer to have
+// zero padding columns wherever a tile sticks out of `cols` (they stay zero: W = T^T V^T 0 = 0).
+template <int NT>
+__device__ __forceinline__ void qr_trail(double* Y, long ld, int rows32, int j0, int nb, int cb0, const double* Ts) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nrb = (rows32 - j0) >> 4;
+  const double* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  const double* ccol[NT];
+  d4 w0[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) { ccol[q] = Y + (long)(cb0 + 16 * q + l15) * ld + j0 + 4 * g; w0[q] = d4{0, 0, 0, 0}; }
+  const bool vkeep = l15 < nb;
+  // ---- phase A: W0[i][c] = sum_r V[r][i] C[r][c]   (3-stage register ring, loads 2 row blocks ahead)
+  {
+    d4 sv[3], sc[3][NT];
+    auto loadA = [&](int rb, d4& v, d4 (&c)[NT]) {
+      const int rbc = min(rb, nrb - 1);
+      v = *reinterpret_cast<const d4*>(vcol + 16 * rbc);
+#pragma unroll
+      for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const d4*>(ccol[q] + 16 * rbc);
+      const bool keep = vkeep && rb < nrb;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int rho = 4 * g + e;
+        double x = v[e];
+        x = (rb == 0) ? ((rho > l15) ? x : ((rho == l15) ? 1.0 : 0.0)) : x;   // unit lower-trapezoidal head
+        v[e] = keep ? x : 0.0;
+      }
+    };
+    auto compA = [&](const d4& v, const d4 (&c)[NT]) {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int q = 0; q < NT; q++) w0[q] = mfma(v[e], c[q][e], w0[q]);
+    };
+    loadA(0, sv[0], sc[0]);
+    loadA(1, sv[1], sc[1]);
+    for (int rb = 0; rb < nrb; rb += 3) {
+      loadA(rb + 2, sv[2], sc[2]); compA(sv[0], sc[0]);
+      loadA(rb + 3, sv[0], sc[0]); compA(sv[1], sc[1]);
+      loadA(rb + 4, sv[1], sc[1]); compA(sv[2], sc[2]);
+    }
+  }
+  // ---- phase B: W = T^T W0   (A[i'][k] = T[k][i'], B k-step s = reg s of W0)
+  d4 w[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    w[q] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) w[q] = mfma(Ts[(4 * s + g) + 16 * l15], w0[q][s], w[q]);
+  }
+  // ---- phase C: C^T[c][r] -= sum_k W[k][c] V[r][k].  Stages of 32 rows aligned to 32: lane l15 owns rows
+  //      (2*l15, 2*l15+1) of the stage -> every access is 16 B/lane and a full 128-B line per column.
+  {
+    const int jb = j0 & ~31;
+    const int nst = (rows32 - jb) >> 5;
+    for (int st = 0; st < nst; st++) {
+      const int row = jb + 32 * st + 2 * l15;
+      d2 v[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        const int k = 4 * s2 + g;               // reflector index
+        d2 x = *reinterpret_cast<const d2*>(Y + (long)(j0 + k) * ld + row);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int rho = row + e - j0;         // row relative to the panel's diagonal block
+          double xe = x[e];
+          xe = (rho < 16) ? ((rho > k) ? xe : ((rho == k) ? 1.0 : 0.0)) : xe;
+          x[e] = (k < nb && rho >= 0) ? xe : 0.0;
+        }
+        v[s2] = x;
+      }
+      d2 c[NT][4];
+#pragma unroll
+      for (int q = 0; q < NT; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          c[q][r] = *reinterpret_cast<const d2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
+#pragma unroll
+      for (int q = 0; q < NT; q++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          d4 acc = d4{c[q][0][e], c[q][1][e], c[q][2][e], c[q][3][e]};
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++) acc = mfma(-w[q][s2], v[s2][e], acc);
+#pragma unroll
+          for (int r = 0; r < 4; r++) c[q][r][e] = acc[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          *reinterpret_cast<d2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[q][r];
+      }
+    }
+  }
+}
+
+// `big`: >= WG_WAVES*256 doubles of LDS scratch (may alias the gemm tile buffers)
+__device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double* big, Prof* pr = nullptr,
+                     unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   double* red = lds;                    // [WG_WAVES*16]
   double* Ts = lds + WG_WAVES * 16;     // [16*16] T, column-major Ts[i + 16*j]
   double* tau = Ts + 256;               // [16]
-  double* bc = tau + 16;                // broadcast scratch [32]
+  double* bc = tau + 16;                // broadcast scratch [64 + 32]
   const int kmax = min(rows, cols);
   const int rows16 = (rows + 15) & ~15;
-  const int ctiles = (cols + 15) >> 4;
+  const int rows32 = (rows + 31) & ~31;      // ld >= rows32, rows [rows, rows32) zero
 
   for (int j0 = 0; j0 < kmax; j0 += QR_NB) {
     const int nb = min(QR_NB, kmax - j0);
-    // zero T
     if (tid < 256) Ts[tid] = 0.0;
     if (tid < 16) tau[tid] = 0.0;
     __syncthreads();
-    // ------------------------------------------------------------------ panel factorisation
-    for (int jj = 0; jj < nb; jj++) {
-      const int col = j0 + jj;
-      double* x = Y + (long)col * ld;
-      // norm of x[col+1:rows]
-      double ss = 0.0;
-      for (int r = col + 1 + tid; r < rows; r += WG_THREADS) { double v = x[r]; ss += v * v; }
-      ss = wg_sum(ss, red);
-      const double alpha = x[col];
-      double beta, tj, scale;
-      if (ss == 0.0) { beta = alpha; tj = 0.0; scale = 0.0; }
-      else {
-        beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-        tj = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-      }
-      __syncthreads();   // everyone has read alpha
-      // scale v in place, v[col] implicitly 1; store beta on the diagonal
-      for (int r = col + 1 + tid; r < rows; r += WG_THREADS) x[r] *= scale;
-      if (tid == 0) { x[col] = beta; tau[jj] = tj; }
-      __syncthreads();
-      // dots of v with the other 15 panel columns: c>jj -> w_c (apply), c<jj -> z_c (T factor)
-      double part[QR_NB];
-#pragma unroll
-      for (int c = 0; c < QR_NB; c++) part[c] = 0.0;
-      for (int r = col + 1 + tid; r < rows; r += WG_THREADS) {
-        const double v = x[r];
-#pragma unroll
-        for (int c = 0; c < QR_NB; c++)
-          if (c != jj && c < nb) part[c] += v * Y[(long)(j0 + c) * ld + r];
-      }
-#pragma unroll
-      for (int c = 0; c < QR_NB; c++) part[c] = wave_sum(part[c]);
-      if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < QR_NB; c++) red[wave * 16 + c] = part[c];
-      }
-      __syncthreads();
-      if (tid < 16) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < WG_WAVES; w++) s += red[w * 16 + tid];
-        // add the row `col` term (v[col] = 1)
-        if (tid < nb && tid != jj) s += Y[(long)(j0 + tid) * ld + col];
-        bc[tid] = s;
-      }
-      __syncthreads();
-      // apply H to the remaining panel columns
-      for (int c = jj + 1; c < nb; c++) {
-        const double w = tj * bc[c];
-        double* yc = Y + (long)(j0 + c) * ld;
-        for (int r = col + 1 + tid; r < rows; r += WG_THREADS) yc[r] -= w * x[r];
-        if (tid == 0) yc[col] -= w;
-      }
-      // T(0:jj, jj) = -tau * T(0:jj,0:jj) * z(0:jj)
-      if (tid < jj) {
-        double s = 0.0;
-        for (int i2 = tid; i2 < jj; i2++) s += Ts[tid + 16 * i2] * bc[i2];
-        Ts[tid + 16 * jj] = -tj * s;
-      }
-      if (tid == 0) Ts[jj + 16 * jj] = tj;
-      __syncthreads();
-    }
+    if (rows - j0 <= QR_RS * WG_THREADS) {
+      qr_panel_regs(Y, ld, rows, j0, nb, red, tau, bc);
+      qr_build_T(Y, ld, rows16, j0, nb, Ts, tau, big);
+    } else qr_panel_global(Y, ld, rows, j0, nb, red, Ts, tau, bc);
+    if (pr) prof_mark(pr, *plast, ph_panel);
     // ------------------------------------------------------------------ trailing update
-    const int ct0 = (j0 + nb + 15) >> 4;         // first full column tile right of the panel ...
-    // ... but columns j0+nb .. 16*ct0 (same tile as the panel when nb < 16) also need the update:
-    // nb < 16 only happens for the last panel (kmax reached); then remaining columns [j0+nb, cols)
-    // may start inside the panel's own tile.  Handle generally: tiles start at column j0+nb.
     const int cstart = j0 + nb;
     const int ntl = (cols - cstart + 15) / 16;   // tiles of 16 columns starting at cstart (may be 0)
-    for (int tl = wave; tl < ntl; tl += WG_WAVES) {
-      const int cb = cstart + tl * 16;           // first column of this tile
-      // columns beyond `cols` inside the tile are padding (zero) as long as cb+15 < cols16 + ... ;
-      // guard explicitly: lane's column valid?
-      const bool cval_row = (cb + l15) < cols;   // for W0 (column index = l15)
-      // ---- phase A: W0[i][c] = sum_r V[r][i] C[r][c]
-      d4 w0 = d4{0, 0, 0, 0};
-      for (int rb = j0; rb < rows16; rb += 16) {
-        const int rr = rb + 4 * g;               // this lane's 4 consecutive rows
-        d4 v = *reinterpret_cast<const d4*>(Y + (long)(j0 + l15) * ld + rr);
-        d4 c = cval_row ? *reinterpret_cast<const d4*>(Y + (long)(cb + l15) * ld + rr) : d4{0, 0, 0, 0};
-        if (rb == j0) {   // unit lower-trapezoidal head of V
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            int rho = 4 * g + e;
-            v[e] = (rho > l15) ? v[e] : ((rho == l15) ? 1.0 : 0.0);
-          }
-        }
-        if (l15 >= nb) v = d4{0, 0, 0, 0};
-#pragma unroll
-        for (int e = 0; e < 4; e++) w0 = mfma(v[e], c[e], w0);
-      }
-      // ---- phase B: W = T^T W0   (A[i'][k] = T[k][i'], B k-step s = reg s of W0)
-      d4 w = d4{0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < 4; s++) w = mfma(Ts[(4 * s + g) + 16 * l15], w0[s], w);
-      // ---- phase C: C^T[c][r] -= sum_k W[k][c] V[r][k]
-      for (int rb = j0; rb < rows16; rb += 16) {
-        d4 acc;
-        const int row = rb + l15;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          int cc = cb + g + 4 * r;
-          acc[r] = (cc < cols) ? Y[(long)cc * ld + row] : 0.0;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int k = 4 * s + g;               // reflector index
-          double v = Y[(long)(j0 + k) * ld + row];
-          if (rb == j0) v = (l15 > k) ? v : ((l15 == k) ? 1.0 : 0.0);
-          if (k >= nb) v = 0.0;
-          acc = mfma(-w[s], v, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          int cc = cb + g + 4 * r;
-          if (cc < cols && row < rows) Y[(long)cc * ld + row] = acc[r];
-        }
-      }
+    // contiguous, balanced tile ranges per wave, in groups of up to QR_TC tiles
+    const int tbase = ntl / WG_WAVES, trem = ntl % WG_WAVES;
+    const int tcnt = tbase + (wave < trem ? 1 : 0);
+    const int tstart = wave * tbase + min(wave, trem);
+    for (int tg = 0; tg < tcnt; tg += QR_TC) {
+      const int nt = min(QR_TC, tcnt - tg);
+      const int cb0 = cstart + (tstart + tg) * 16;
+      if (nt == 1) qr_trail<1>(Y, ld, rows32, j0, nb, cb0, Ts);
+      else if (nt == 2) qr_trail<2>(Y, ld, rows32, j0, nb, cb0, Ts);
+      else if (nt == 3) qr_trail<3>(Y, ld, rows32, j0, nb, cb0, Ts);
+      else qr_trail<4>(Y, ld, rows32, j0, nb, cb0, Ts);
     }
-    (void)ct0; (void)ctiles;
     __syncthreads();
+    if (pr) prof_mark(pr, *plast, ph_trail);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// One-sided Jacobi (Hestenes): A (m x n, ld lda) -> A V = U Sigma; V (n x n, ld ldv) accumulated from I.
+// One-sided Jacobi (Hestenes): A (m x n, ld lda) -> A V = U Sigma; V (n x n, ld ldv) accumulated from I
+// (V == nullptr: not accumulated - the rotated columns sigma_j u_j then carry the LEFT singular vectors).
 // Column norms of the final A are the singular values (unsorted).  8 lanes per column pair.
 // Returns number of sweeps used (all threads), or -1 if not converged in maxsweeps.
 // n is padded to even internally via a virtual zero column (skipped).  `red`: >= 16 doubles.
 // A and V may live in LDS or global memory (generic pointers).
 // ---------------------------------------------------------------------------------------------
 __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, double* red, int maxsweeps) {
+  // lda / ldv should be odd (LDS bank spreading between the column pairs of different lane groups)
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < n * n; idx += WG_THREADS) {
-    int r = idx % n, c = idx / n;
-    V[r + (long)ldv * c] = (r == c) ? 1.0 : 0.0;
+  if (V) {
+    for (int idx = tid; idx < n * n; idx += WG_THREADS) {
+      int r = idx % n, c = idx / n;
+      V[r + (long)ldv * c] = (r == c) ? 1.0 : 0.0;
+    }
   }
   __syncthreads();
   if (n < 2) return 0;
@@ -415,9 +654,11 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
               const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
               const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
               for (int r = sub; r < m; r += 8) { double x = ap[r], y = aq[r]; ap[r] = c * x - s * y; aq[r] = s * x + c * y; }
-              double* vp = V + (long)ldv * p;
-              double* vq = V + (long)ldv * q;
-              for (int r = sub; r < n; r += 8) { double x = vp[r], y = vq[r]; vp[r] = c * x - s * y; vq[r] = s * x + c * y; }
+              if (V) {
+                double* vp = V + (long)ldv * p;
+                double* vq = V + (long)ldv * q;
+                for (int r = sub; r < n; r += 8) { double x = vp[r], y = vq[r]; vp[r] = c * x - s * y; vq[r] = s * x + c * y; }
+              }
             }
           }
         }

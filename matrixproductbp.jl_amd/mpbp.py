@@ -293,17 +293,23 @@ class MPBP:
         _lib.check(self._L.mpbp_get_bonds(self._h, _ip(b)), self._h)
         return b
 
-    def get_messages(self):
-        """list over edges of lists over t of arrays [b_t, b_{t+1}, q, q] (`bp.μ`)."""
+    def get_messages(self, edges=None):
+        """list over edges of lists over t of arrays [b_t, b_{t+1}, q, q] (`bp.μ`); `edges` restricts the
+        download (other entries are None)."""
         b = self.bonds()
-        q = self.q
+        q, E = self.q, self.g.ne()
+        sel = np.ones(E, dtype=bool) if edges is None else np.isin(np.arange(E), np.asarray(edges))
         sizes = (b[:, :-1].astype(np.int64) * b[:, 1:] * q * q)
-        offs = np.zeros(self.g.ne(), dtype=np.int64)
-        offs[1:] = np.cumsum(sizes.sum(axis=1))[:-1]
-        data = np.zeros(int(sizes.sum()))
+        tot = np.where(sel, sizes.sum(axis=1), 0)
+        offs = np.concatenate([[0], np.cumsum(tot)[:-1]]).astype(np.int64)
+        offs[~sel] = -1
+        data = np.zeros(int(tot.sum()))
         _lib.check(self._L.mpbp_get_messages(self._h, offs.ctypes.data_as(C.POINTER(C.c_int64)), _dp(data)), self._h)
         out = []
-        for e in range(self.g.ne()):
+        for e in range(E):
+            if not sel[e]:
+                out.append(None)
+                continue
             o, cores = int(offs[e]), []
             for t in range(self.T + 1):
                 n = int(sizes[e, t])

@@ -307,6 +307,56 @@ def f_bp_partial_i(A, wi, phi_i, d):
     return _f_bp_partial(A, wi, phi_i, d, "prob_y_dummy", 1, 1)
 
 
+def op_kron_compress(wi, a, b, T, svd_trunc):
+    """The `op` closure of compute_prob_ys (recursive_bp_factor.jl:118-131): Kronecker product of two
+    ỹ-messages through prob_yy, compress!, normalize_eachmatrix!.  `a`, `b` are (train, d) pairs."""
+    B1, d1 = a
+    B2, d2 = b
+    cores = []
+    for t in range(T + 1):
+        w = wi[t]
+        b1, b2 = B1[t], B2[t]
+        ny = w.nstates(d1 + d2)
+        Pyy = np.zeros((ny, b1.shape[2], b2.shape[2], b1.shape[3]))
+        for y in range(ny):
+            for y1 in range(b1.shape[2]):
+                for y2 in range(b2.shape[2]):
+                    for xi in range(b1.shape[3]):
+                        Pyy[y, y1, y2, xi] = w.prob_yy(y + 1, y1 + 1, y2 + 1, xi + 1, d1, d2)
+        B3 = np.einsum("yabx,ipax,jqbx->ijpqyx", Pyy, b1, b2, optimize=True)       # [m1,m2,n1,n2,y,x]
+        s = B3.shape
+        cores.append(B3.reshape(s[0] * s[1], s[2] * s[3], s[4], s[5], order="F"))
+    Bout = TensorTrain(cores, B1.logz + B2.logz)
+    compress(Bout, svd_trunc)
+    normalize_eachmatrix(Bout)
+    return Bout, d1 + d2
+
+
+def prob_xy_apply(wi, qi, mu_k, psi_k, k, T):
+    """One ỹ-message B_k of compute_prob_ys (recursive_bp_factor.jl:108-115), k 0-based."""
+    cores = []
+    for t in range(T + 1):
+        w = wi[t]
+        mk = mu_k[t]
+        ny1 = w.nstates(1)
+        qk = mk.shape[2]
+        Pxy = np.zeros((ny1, qk, qi))
+        for y in range(ny1):
+            for xk in range(qk):
+                for xi in range(qi):
+                    Pxy[y, xk, xi] = w.prob_xy(y + 1, xk + 1, xi + 1, k + 1) * psi_k[t][xi, xk]
+        cores.append(np.einsum("ykx,mnkx->mnyx", Pxy, mk))
+    return TensorTrain(cores, mu_k.logz), 1
+
+
+def init_train(wi, qi, T):
+    """recursive_bp_factor.jl:133-138"""
+    Minit = [np.array([[float(wi[t].prob_y0(y + 1, xi + 1)) for xi in range(qi)]
+                       for y in range(wi[t].nstates(0))]).reshape(1, 1, wi[t].nstates(0), qi)
+             for t in range(T + 1)]
+    return TensorTrain(Minit), 0
+
+
 def compute_prob_ys(wi, qi, mu_in, psi_out, T, svd_trunc):
     """recursive_bp_factor.jl:104-143.  Returns (C, full): cavity ỹ-messages and the full one."""
     B = []
@@ -326,26 +376,7 @@ def compute_prob_ys(wi, qi, mu_in, psi_out, T, svd_trunc):
         B.append((TensorTrain(cores, mu_in[k].logz), 1))
 
     def op(a, b):
-        B1, d1 = a
-        B2, d2 = b
-        cores = []
-        for t in range(T + 1):
-            w = wi[t]
-            b1, b2 = B1[t], B2[t]
-            ny = w.nstates(d1 + d2)
-            Pyy = np.zeros((ny, b1.shape[2], b2.shape[2], b1.shape[3]))
-            for y in range(ny):
-                for y1 in range(b1.shape[2]):
-                    for y2 in range(b2.shape[2]):
-                        for xi in range(b1.shape[3]):
-                            Pyy[y, y1, y2, xi] = w.prob_yy(y + 1, y1 + 1, y2 + 1, xi + 1, d1, d2)
-            B3 = np.einsum("yabx,ipax,jqbx->ijpqyx", Pyy, b1, b2, optimize=True)       # [m1,m2,n1,n2,y,x]
-            s = B3.shape
-            cores.append(B3.reshape(s[0] * s[1], s[2] * s[3], s[4], s[5], order="F"))
-        Bout = TensorTrain(cores, B1.logz + B2.logz)
-        compress(Bout, svd_trunc)
-        normalize_eachmatrix(Bout)
-        return Bout, d1 + d2
+        return op_kron_compress(wi, a, b, T, svd_trunc)
 
     Minit = [np.array([[float(wi[t].prob_y0(y + 1, xi + 1)) for xi in range(qi)]
                        for y in range(wi[t].nstates(0))]).reshape(1, 1, wi[t].nstates(0), qi)
