@@ -1,0 +1,72 @@
+"""Generates the golden fixtures of tests/golden/ from the CPU oracle (and stores the reference's own
+hard-coded known answer verbatim).  Run from the repo root:  python tests/golden/make_golden.py
+The reference itself is Julia and cannot run in this image, so fixtures are (a) the numbers the reference's
+tests hold (test/sis_infinite_graph.jl:21-29) and (b) oracle outputs on seeded inputs, the oracle being pinned
+to (a) and to brute-force enumeration by tests/test_oracle.py."""
+import json
+import os
+import sys
+
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import networkx as nx  # noqa: E402
+import numpy as np  # noqa: E402
+
+from oracle import factors as OF  # noqa: E402
+from oracle import mpbp as O  # noqa: E402
+from oracle import tensor_trains as OT  # noqa: E402
+from oracle.exact import exact_marginals, exact_pair_marginals, exact_prob  # noqa: E402
+
+
+def known_answer():
+    ref = [[0.9000000001671186, 0.0999999998328814], [0.8932690998131098, 0.10673090018689023],
+           [0.8899420329322244, 0.11005796706777556], [0.8884643888492034, 0.11153561115079656],
+           [0.8880305235706524, 0.1119694764293476], [0.8882121515614524, 0.11178784843854758],
+           [0.8887717202217936, 0.1112282797782064]]
+    json.dump({"source": "reference test/sis_infinite_graph.jl:1-30 (verbatim)",
+               "params": {"T": 6, "k": 3, "gamma": 0.1, "lambda": 0.1, "rho": 0.2, "svd_trunc": "TruncBond(10)",
+                          "maxiter": 200, "tol": 1e-14},
+               "beliefs": ref}, open(os.path.join(HERE, "sis_infinite_graph_reference.json"), "w"), indent=1)
+
+
+def rrg_sweeps():
+    N, T, Mb, sweeps = 16, 10, 8, 3
+    lam, rho, gam = 0.1, 0.05, 0.1
+    A = nx.to_numpy_array(nx.random_regular_graph(3, N, seed=0), nodelist=range(N))
+    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    bp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    out = {"A": A, "params": np.array([N, T, Mb, sweeps, lam, rho, gam])}
+    for s in range(sweeps):
+        O.iterate(bp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
+        out[f"beliefs_{s}"] = np.array(O.beliefs(bp))
+        out[f"f_{s}"] = bp.f.copy()
+    pb, lz = O.pair_beliefs(bp)
+    out["pair_beliefs"] = np.array(pb)
+    out["pair_logz"] = lz
+    out["bonds"] = np.array([m.bonds for m in bp.mu])
+    np.savez_compressed(os.path.join(HERE, "sis_rrg16_T10_M8_jacobi.npz"), **out)
+
+
+def star_exact():
+    T = 3
+    A = np.array([[0, 1, 1, 1], [1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0]])
+    lam, rho, gam, alpha = 0.5, 0.4, 0.5, 0.1
+    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(4)]
+    rng = np.random.default_rng(111)
+    for i in range(4):
+        phi[i][T] = np.array([1.0, 0.0]) if rng.random() < 0.5 else np.array([0.0, 1.0])
+    bp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, [2] * 4, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(bp)
+    np.savez_compressed(os.path.join(HERE, "sis_star4_T3_exact.npz"), A=A, phi=np.array(phi),
+                        params=np.array([T, lam, rho, gam, alpha]), marginals=np.array(exact_marginals(bp, p)),
+                        pair_marginals=np.array(exact_pair_marginals(bp, p)), Z=Z)
+
+
+if __name__ == "__main__":
+    known_answer()
+    rrg_sweeps()
+    star_exact()
+    print(sorted(os.listdir(HERE)))

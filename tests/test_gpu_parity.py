@@ -168,3 +168,33 @@ def test_error_paths_do_not_abort():
         M.onebpiter(bp, [0, 0], M.TruncBond(4))
     with pytest.raises(M.MPBPError):
         M.onebpiter(bp, [7], M.TruncBond(4))
+
+
+def test_full_size_config2_properties():
+    """BASELINE configs[1] at full size (N=1024, T=50, bond 20): size-independent properties after 3 Jacobi
+    sweeps (the oracle would need hours here): normalised beliefs, transposed pair beliefs on reverse edges,
+    bounded bonds, finite free energy, no NaN / capacity / Jacobi flags."""
+    N, T, Mb = 1024, 50, 20
+    A = nx.to_numpy_array(nx.random_regular_graph(3, N, seed=0), nodelist=range(N))
+    gam = 0.1
+    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    g = M.IndexedBiDiGraph(A)
+    bp = M.mpbp(g, [[M.SISFactor(0.1, 0.05)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    for _ in range(3):
+        M.onebpiter(bp, np.arange(N, dtype=np.int32), M.TruncBond(Mb))
+        st = bp.last_stats
+        assert st.nan_flag == 0 and st.capacity_flag == 0 and st.jacobi_not_converged == 0
+    assert st.n_compress == N * (7 + 3)
+    b = np.array(M.beliefs(bp))
+    assert np.isfinite(b).all() and (b >= -1e-12).all() and np.abs(b.sum(axis=2) - 1).max() < 1e-12
+    assert np.abs(b[:, 0, 1] - gam).max() < 1e-9          # time-0 marginal is the prior (no observations)
+    bonds = bp.bonds()
+    assert bonds.max() == Mb and (bonds[:, 0] == 1).all() and (bonds[:, -1] == 1).all()
+    pb, lz = M.pair_beliefs(bp)
+    pb = np.array(pb)
+    assert np.abs(pb.sum(axis=(2, 3)) - 1).max() < 1e-12
+    rev = g.rev
+    assert np.abs(pb - np.transpose(pb[rev], (0, 1, 3, 2))).max() < 1e-10
+    assert np.isfinite(M.bethe_free_energy(bp))
+    # without observations the SIS prior is normalised: Z = 1  =>  F -> 0 as BP converges; already small
+    assert abs(M.bethe_free_energy(bp)) < 1e-2 * N
