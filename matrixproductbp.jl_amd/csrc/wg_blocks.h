@@ -231,8 +231,9 @@ __device__ inline double wg_maxabs(const double* A, long ld, int rows, int cols,
 // ---------------------------------------------------------------------------------------------
 constexpr int QR_NB = 16;
 constexpr int QR_RS = 4;      // rows per thread of the register panel
-constexpr int QR_TC = 4;      // column tiles a wave updates together
-constexpr int QR_LDS_DOUBLES = WG_WAVES * 16 + 16 * 16 + 16 + 2 * 32 + 2 * 16;
+constexpr int QR_TC = 3;      // column tiles a wave updates together
+constexpr int QR_LDS_BASE = WG_WAVES * 16 + 16 * 16 + 16 + 2 * 32 + 2 * 16;
+constexpr int QR_LDS_DOUBLES = QR_LDS_BASE + 256 + 256 + 16;
 
 // 16 per-lane partial values -> lanes with (lane & 3) == 0 hold the wave total of value
 // idx = ((lane>>5)&1)<<3 | ((lane>>4)&1)<<2 | ((lane>>3)&1)<<1 | ((lane>>2)&1)   (17 shuffles instead of 96)
@@ -344,49 +345,73 @@ __device__ __attribute__((noinline)) void qr_panel_regs(double* Y, long ld, int 
   __syncthreads();
 }
 
-// T of the block reflector from the Gram matrix of V (dlarft recurrence with z = G(0:j, j)):
-//   G = V^T V by MFMA (every wave takes the row blocks rb = wave, wave+8, ...), reduced through `big`
-//   (>= WG_WAVES*256 doubles of LDS), then T(0:j,j) = -tau_j T(0:j,0:j) G(0:j,j), T(j,j) = tau_j.
-__device__ __forceinline__ void qr_build_T(const double* Y, long ld, int rows16, int j0, int nb, double* Ts,
-                                           const double* tau, double* big) {
+// G[i + 16 j] = sum_r Vx[r][i] Vy[r][j] over the rows from `jrow` (a multiple of 16) by MFMA: every wave takes
+// the row blocks rb = wave, wave+8, ...; partials are reduced through `big` (>= WG_WAVES*256 doubles of LDS).
+// Vx / Vy are panels stored in place (unit lower-trapezoidal heads at column offsets jx / jy, nbx / nby
+// reflectors).  Result in big[0..255]; ends with a barrier.
+__device__ __forceinline__ void qr_gram(const double* Y, long ld, int rows32, int jrow, int jx, int nbx, int jy,
+                                        int nby, double* big) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  const int nrb = (rows16 - j0) >> 4;
-  const double* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  const int nrb = (rows32 - jrow) >> 4;
+  const double* xcol = Y + (long)(jx + l15) * ld + jrow + 4 * g;
+  const double* ycol = Y + (long)(jy + l15) * ld + jrow + 4 * g;
   d4 acc = d4{0, 0, 0, 0};
   for (int rb = wave; rb < nrb; rb += WG_WAVES) {
-    d4 v = *reinterpret_cast<const d4*>(vcol + 16 * rb);
-    if (rb == 0) {
+    d4 vx = *reinterpret_cast<const d4*>(xcol + 16 * rb);
+    d4 vy = *reinterpret_cast<const d4*>(ycol + 16 * rb);
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int rho = 4 * g + e;
-        v[e] = (rho > l15) ? v[e] : ((rho == l15) ? 1.0 : 0.0);
-      }
+    for (int e = 0; e < 4; e++) {
+      const int row = jrow + 16 * rb + 4 * g + e;
+      const int rx = row - jx, ry = row - jy;       // relative to each panel's diagonal block
+      double a = vx[e], b = vy[e];
+      a = (rx < 16) ? ((rx > l15) ? a : ((rx == l15) ? 1.0 : 0.0)) : a;
+      b = (ry < 16) ? ((ry > l15) ? b : ((ry == l15) ? 1.0 : 0.0)) : b;
+      vx[e] = (l15 < nbx && rx >= 0) ? a : 0.0;
+      vy[e] = (l15 < nby && ry >= 0) ? b : 0.0;
     }
-    if (l15 >= nb) v = d4{0, 0, 0, 0};
 #pragma unroll
-    for (int e = 0; e < 4; e++) acc = mfma(v[e], v[e], acc);
+    for (int e = 0; e < 4; e++) acc = mfma(vx[e], vy[e], acc);
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) big[wave * 256 + (g + 4 * r) + 16 * l15] = acc[r];
   __syncthreads();
+  double sacc = 0.0;
   if (tid < 256) {
-    double sacc = 0.0;
 #pragma unroll
     for (int w = 0; w < WG_WAVES; w++) sacc += big[w * 256 + tid];
-    big[tid] = sacc;        // G[i + 16 j]   (safe: every thread reads column `tid` of all waves first)
   }
   __syncthreads();
-  for (int j = 0; j < nb; j++) {
-    const double tj = tau[j];
-    if (tid < j) {
-      double sacc = 0.0;
-      for (int i2 = tid; i2 < j; i2++) sacc += Ts[tid + 16 * i2] * big[i2 + 16 * j];
-      Ts[tid + 16 * j] = -tj * sacc;
+  if (tid < 256) big[tid] = sacc;
+  __syncthreads();
+}
+
+// T of the block reflector (dlarft) from the Gram matrix G = V^T V in `big`: row i of T depends only on its own
+// earlier entries, so lane i builds row i in registers with no synchronisation:
+//   T(i,j) = -tau_j sum_{i2=i}^{j-1} T(i,i2) G(i2,j)  (i < j),  T(j,j) = tau_j.
+__device__ __forceinline__ void qr_T_from_gram(const double* big, const double* tau, int nb, double* Ts) {
+  const int tid = threadIdx.x;
+  if (tid < 16) {
+    double trow[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      double v = 0.0;
+      if (j < nb) {
+        if (j == tid) v = tau[j];
+        else if (j > tid) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int i2 = 0; i2 < 16; i2++)
+            if (i2 >= tid && i2 < j) sacc += trow[i2] * big[i2 + 16 * j];
+          v = -tau[j] * sacc;
+        }
+      }
+      trow[j] = v;
     }
-    if (tid == 0) Ts[j + 16 * j] = tj;
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) Ts[tid + 16 * j] = trow[j];
   }
+  __syncthreads();
 }
 
 // generic panel factorisation, panel in global memory (any number of rows)
@@ -549,6 +574,189 @@ __device__ __forceinline__ void qr_trail(double* Y, long ld, int rows32, int j0,
   }
 }
 
+// Trailing update by TWO adjacent panels a (columns j0..j0+15) and b (j0+16..j0+31, nbb reflectors) in one
+// pass over the rows (half the HBM traffic of two single-panel passes):
+//   (I - Vb Tb^T Vb^T)(I - Va Ta^T Va^T) C = C - Va Wa - Vb Wb,
+//   Wa = Ta^T Va^T C,   Wb = Tb^T (Vb^T C - S Wa),   S = Vb^T Va  (16x16, in LDS).
+template <int NT>
+__device__ __forceinline__ void qr_trail2(double* Y, long ld, int rows32, int j0, int nbb, int cb0,
+                                          const double* TsA, const double* TsB, const double* Sm) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nrb = (rows32 - j0) >> 4;
+  const double* vacol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  const double* vbcol = Y + (long)(j0 + 16 + l15) * ld + j0 + 4 * g;
+  const double* ccol[NT];
+  d4 wa0[NT], wb0[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    ccol[q] = Y + (long)(cb0 + 16 * q + l15) * ld + j0 + 4 * g;
+    wa0[q] = d4{0, 0, 0, 0}; wb0[q] = d4{0, 0, 0, 0};
+  }
+  const bool bkeep = l15 < nbb;
+  {
+    d4 sa[3], sb[3], sc[3][NT];
+    auto loadA = [&](int rb, d4& va, d4& vb, d4 (&c)[NT]) {
+      const int rbc = min(rb, nrb - 1);
+      va = *reinterpret_cast<const d4*>(vacol + 16 * rbc);
+      vb = *reinterpret_cast<const d4*>(vbcol + 16 * rbc);
+#pragma unroll
+      for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const d4*>(ccol[q] + 16 * rbc);
+      const bool in = rb < nrb;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int rho = 4 * g + e;
+        double a = va[e], b = vb[e];
+        a = (rb == 0) ? ((rho > l15) ? a : ((rho == l15) ? 1.0 : 0.0)) : a;
+        b = (rb == 1) ? ((rho > l15) ? b : ((rho == l15) ? 1.0 : 0.0)) : b;
+        va[e] = in ? a : 0.0;
+        vb[e] = (in && bkeep && rb >= 1) ? b : 0.0;
+      }
+    };
+    auto compA = [&](const d4& va, const d4& vb, const d4 (&c)[NT]) {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int q = 0; q < NT; q++) { wa0[q] = mfma(va[e], c[q][e], wa0[q]); wb0[q] = mfma(vb[e], c[q][e], wb0[q]); }
+    };
+    loadA(0, sa[0], sb[0], sc[0]);
+    loadA(1, sa[1], sb[1], sc[1]);
+    for (int rb = 0; rb < nrb; rb += 3) {
+      loadA(rb + 2, sa[2], sb[2], sc[2]); compA(sa[0], sb[0], sc[0]);
+      loadA(rb + 3, sa[0], sb[0], sc[0]); compA(sa[1], sb[1], sc[1]);
+      loadA(rb + 4, sa[1], sb[1], sc[1]); compA(sa[2], sb[2], sc[2]);
+    }
+  }
+  // phase B
+  d4 wa[NT], wb[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    wa[q] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) wa[q] = mfma(TsA[(4 * s + g) + 16 * l15], wa0[q][s], wa[q]);
+    d4 t = wb0[q];                          // t = Vb^T C - S Wa
+#pragma unroll
+    for (int s = 0; s < 4; s++) t = mfma(-Sm[l15 + 16 * (4 * s + g)], wa[q][s], t);
+    wb[q] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) wb[q] = mfma(TsB[(4 * s + g) + 16 * l15], t[s], wb[q]);
+  }
+  // phase C
+  {
+    const int jb = j0 & ~31;
+    const int nst = (rows32 - jb) >> 5;
+    for (int st = 0; st < nst; st++) {
+      const int row = jb + 32 * st + 2 * l15;
+      d2 va[4], vb[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        const int k = 4 * s2 + g;
+        d2 xa = *reinterpret_cast<const d2*>(Y + (long)(j0 + k) * ld + row);
+        d2 xb = *reinterpret_cast<const d2*>(Y + (long)(j0 + 16 + k) * ld + row);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int ra = row + e - j0, rbb = row + e - j0 - 16;
+          double a = xa[e], b = xb[e];
+          a = (ra < 16) ? ((ra > k) ? a : ((ra == k) ? 1.0 : 0.0)) : a;
+          b = (rbb < 16) ? ((rbb > k) ? b : ((rbb == k) ? 1.0 : 0.0)) : b;
+          xa[e] = (ra >= 0) ? a : 0.0;
+          xb[e] = (k < nbb && rbb >= 0) ? b : 0.0;
+        }
+        va[s2] = xa; vb[s2] = xb;
+      }
+      d2 c[NT][4];
+#pragma unroll
+      for (int q = 0; q < NT; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          c[q][r] = *reinterpret_cast<const d2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
+#pragma unroll
+      for (int q = 0; q < NT; q++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          d4 acc = d4{c[q][0][e], c[q][1][e], c[q][2][e], c[q][3][e]};
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++) { acc = mfma(-wa[q][s2], va[s2][e], acc); acc = mfma(-wb[q][s2], vb[s2][e], acc); }
+#pragma unroll
+          for (int r = 0; r < 4; r++) c[q][r][e] = acc[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          *reinterpret_cast<d2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[q][r];
+      }
+    }
+  }
+}
+
+// Update ONE 16-column tile (first column cb0) by panel (j0, nb) with all waves working on different rows:
+// W0 partials -> LDS, every wave then applies W = T^T W0 to its own 32-row stages.
+__device__ __forceinline__ void qr_tile_update_all(double* Y, long ld, int rows32, int j0, int nb, int cb0,
+                                                   const double* Ts, double* big) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nrb = (rows32 - j0) >> 4;
+  const double* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  const double* ccol = Y + (long)(cb0 + l15) * ld + j0 + 4 * g;
+  d4 acc = d4{0, 0, 0, 0};
+  for (int rb = wave; rb < nrb; rb += WG_WAVES) {
+    d4 v = *reinterpret_cast<const d4*>(vcol + 16 * rb);
+    d4 c = *reinterpret_cast<const d4*>(ccol + 16 * rb);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rho = 4 * g + e;
+      double x = v[e];
+      x = (rb == 0) ? ((rho > l15) ? x : ((rho == l15) ? 1.0 : 0.0)) : x;
+      v[e] = (l15 < nb) ? x : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc = mfma(v[e], c[e], acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) big[wave * 256 + (g + 4 * r) + 16 * l15] = acc[r];
+  __syncthreads();
+  // every wave sums the partials into its own W0 registers (C layout: row g+4r, col l15)
+  d4 w0 = d4{0, 0, 0, 0};
+#pragma unroll
+  for (int w = 0; w < WG_WAVES; w++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) w0[r] += big[w * 256 + (g + 4 * r) + 16 * l15];
+  d4 wv = d4{0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 4; s++) wv = mfma(Ts[(4 * s + g) + 16 * l15], w0[s], wv);
+  const int jb = j0 & ~31;
+  const int nst = (rows32 - jb) >> 5;
+  for (int st = wave; st < nst; st += WG_WAVES) {
+    const int row = jb + 32 * st + 2 * l15;
+    d2 v[4], c[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) {
+      const int k = 4 * s2 + g;
+      d2 x = *reinterpret_cast<const d2*>(Y + (long)(j0 + k) * ld + row);
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int rho = row + e - j0;
+        double xe = x[e];
+        xe = (rho < 16) ? ((rho > k) ? xe : ((rho == k) ? 1.0 : 0.0)) : xe;
+        x[e] = (k < nb && rho >= 0) ? xe : 0.0;
+      }
+      v[s2] = x;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const d2*>(Y + (long)(cb0 + g + 4 * r) * ld + row);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      d4 a = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) a = mfma(-wv[s2], v[s2][e], a);
+#pragma unroll
+      for (int r = 0; r < 4; r++) c[r][e] = a[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) *reinterpret_cast<d2*>(Y + (long)(cb0 + g + 4 * r) * ld + row) = c[r];
+  }
+  __syncthreads();
+}
+
 // `big`: >= WG_WAVES*256 doubles of LDS scratch (may alias the gemm tile buffers)
 __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double* big, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0) {
@@ -562,34 +770,64 @@ __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double
   const int rows16 = (rows + 15) & ~15;
   const int rows32 = (rows + 31) & ~31;      // ld >= rows32, rows [rows, rows32) zero
 
-  for (int j0 = 0; j0 < kmax; j0 += QR_NB) {
+  double* TsB = lds + QR_LDS_BASE;        // second T and the cross Gram S of a panel pair
+  double* Sm = TsB + 256;
+  double* tauB = Sm + 256;
+  const int ncol16 = (cols + 15) >> 4;
+  (void)rows16;
+  for (int j0 = 0; j0 < kmax;) {
     const int nb = min(QR_NB, kmax - j0);
+    const bool fast = rows - j0 <= QR_RS * WG_THREADS;
     if (tid < 256) Ts[tid] = 0.0;
     if (tid < 16) tau[tid] = 0.0;
     __syncthreads();
-    if (rows - j0 <= QR_RS * WG_THREADS) {
+    if (fast) {
       qr_panel_regs(Y, ld, rows, j0, nb, red, tau, bc);
-      qr_build_T(Y, ld, rows16, j0, nb, Ts, tau, big);
+      qr_gram(Y, ld, rows32, j0, j0, nb, j0, nb, big);
+      qr_T_from_gram(big, tau, nb, Ts);
     } else qr_panel_global(Y, ld, rows, j0, nb, red, Ts, tau, bc);
+    // pair with the next panel when both are full-width register panels and a trailing matrix remains
+    const int j1 = j0 + 16;
+    const int nbb = min(QR_NB, kmax - j1);
+    const bool pair = fast && nb == 16 && j1 < kmax && nbb == 16 && (j1 + 16 < cols);
     if (pr) prof_mark(pr, *plast, ph_panel);
+    if (pair) {
+      qr_tile_update_all(Y, ld, rows32, j0, 16, j1, Ts, big);
+      if (pr) prof_mark(pr, *plast, ph_trail);
+      if (tid < 16) tauB[tid] = 0.0;
+      __syncthreads();
+      qr_panel_regs(Y, ld, rows, j1, nbb, red, tauB, bc);
+      qr_gram(Y, ld, rows32, j1, j1, nbb, j1, nbb, big);
+      qr_T_from_gram(big, tauB, nbb, TsB);
+      qr_gram(Y, ld, rows32, j1, j1, nbb, j0, 16, big);     // S = Vb^T Va
+      if (tid < 256) Sm[tid] = big[tid];
+      __syncthreads();
+      if (pr) prof_mark(pr, *plast, ph_panel);
+    }
     // ------------------------------------------------------------------ trailing update
-    const int cstart = j0 + nb;
+    const int cstart = pair ? j1 + 16 : j0 + nb;
     const int ntl = (cols - cstart + 15) / 16;   // tiles of 16 columns starting at cstart (may be 0)
-    // contiguous, balanced tile ranges per wave, in groups of up to QR_TC tiles
     const int tbase = ntl / WG_WAVES, trem = ntl % WG_WAVES;
     const int tcnt = tbase + (wave < trem ? 1 : 0);
     const int tstart = wave * tbase + min(wave, trem);
     for (int tg = 0; tg < tcnt; tg += QR_TC) {
       const int nt = min(QR_TC, tcnt - tg);
       const int cb0 = cstart + (tstart + tg) * 16;
-      if (nt == 1) qr_trail<1>(Y, ld, rows32, j0, nb, cb0, Ts);
-      else if (nt == 2) qr_trail<2>(Y, ld, rows32, j0, nb, cb0, Ts);
-      else if (nt == 3) qr_trail<3>(Y, ld, rows32, j0, nb, cb0, Ts);
-      else qr_trail<4>(Y, ld, rows32, j0, nb, cb0, Ts);
+      if (pair) {
+        if (nt == 1) qr_trail2<1>(Y, ld, rows32, j0, nbb, cb0, Ts, TsB, Sm);
+        else if (nt == 2) qr_trail2<2>(Y, ld, rows32, j0, nbb, cb0, Ts, TsB, Sm);
+        else qr_trail2<3>(Y, ld, rows32, j0, nbb, cb0, Ts, TsB, Sm);
+      } else {
+        if (nt == 1) qr_trail<1>(Y, ld, rows32, j0, nb, cb0, Ts);
+        else if (nt == 2) qr_trail<2>(Y, ld, rows32, j0, nb, cb0, Ts);
+        else qr_trail<3>(Y, ld, rows32, j0, nb, cb0, Ts);
+      }
     }
     __syncthreads();
     if (pr) prof_mark(pr, *plast, ph_trail);
+    j0 += pair ? 32 : 16;
   }
+  (void)ncol16;
 }
 
 // ---------------------------------------------------------------------------------------------
