@@ -198,3 +198,83 @@ def test_full_size_config2_properties():
     assert np.isfinite(M.bethe_free_energy(bp))
     # without observations the SIS prior is normalised: Z = 1  =>  F -> 0 as BP converges; already small
     assert abs(M.bethe_free_energy(bp)) < 1e-2 * N
+
+
+def _karate():
+    import os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "karate.txt")
+    return np.loadtxt(p)
+
+
+def test_sis_karate_heterogeneous_degree_matches_oracle():
+    """BASELINE configs[3] structure (karate club, degrees 1..17 -> cavity DAGs up to 49 ops, 17 levels) at a
+    size the oracle finishes in seconds: T=4, bond 5, 2 Jacobi sweeps, node 0 infected at t=0."""
+    A = _karate()
+    N, T, Mb = A.shape[0], 4, 5
+    assert N == 34 and int(A.sum()) == 156 and int(A.sum(axis=0).max()) == 17
+    phi = [[np.array([0.0, 1.0]) if (t == 0 and i == 0) else (np.array([1.0, 0.0]) if t == 0 else np.ones(2))
+            for t in range(T + 1)] for i in range(N)]
+    lam, rho = 0.1, 0.05
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    for s in range(2):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+    import ctypes as C
+    f = np.zeros(N)
+    bp._L.mpbp_free_energy(bp._h, f.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.abs(f - obp.f).max() < RTOL * max(1.0, np.abs(obp.f).max())
+    assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
+
+
+def test_glauber_erdos_renyi_loopy_matches_oracle():
+    """BASELINE configs[2] structure (homogeneous Glauber on an ER graph: nstates = l+1 grows along the cavity,
+    isolated and degree-1 nodes present) at oracle-feasible size."""
+    G = nx.gnp_random_graph(14, 4 / 13, seed=1)
+    A = nx.to_numpy_array(G, nodelist=range(14))
+    N, T, Mb = 14, 4, 6
+    J = 0.5 * A
+    h = np.zeros(N)
+    m0 = -0.6
+    phi = [[np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    gl = M.Glauber(M.Ising(J, h, 1.0), T, phi=phi)
+    bp = gl.mpbp(max_bond=Mb)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), OF.glauber_factors(A != 0, J, h, 1.0, T), [2] * N, T, phi=phi)
+    for s in range(2):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+    pb, lz = M.pair_beliefs(bp)
+    opb, olz = O.pair_beliefs(obp)
+    assert _rel(_flat(pb), _flat(opb)) < RTOL
+    assert abs(M.bethe_free_energy(bp) - O.bethe_free_energy(obp)) < RTOL * max(1.0, np.abs(obp.f).sum())
+
+
+def test_trunc_thresh_loopy_matches_oracle():
+    """default_truncator = TruncThresh(1e-6) (reference src/mpems.jl:161) on a loopy graph: data-dependent bonds."""
+    N, T = 8, 6
+    lam, rho, gam = 0.2, 0.1, 0.15
+    A, phi = _loopy(N, T, lam, rho, gam)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=16)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    for s in range(3):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncThresh(1e-6), tol=0.0)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncThresh(1e-6), tol=0.0, shuffle_nodes=False, jacobi=True)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+    assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
+
+
+def test_infinite_bipartite_graph_matches_oracle():
+    """reference src/infinite_graph.jl:68-122 (two node types, aliased edges)."""
+    T = 4
+    k = (2, 3)
+    w = [[M.HomogeneousGlauberFactor(0.3, 0.1, 1.0)] * (T + 1), [M.HomogeneousGlauberFactor(0.3, -0.2, 1.0)] * (T + 1)]
+    ow = [[OF.HomogeneousGlauberFactor(0.3, 0.1, 1.0)] * (T + 1), [OF.HomogeneousGlauberFactor(0.3, -0.2, 1.0)] * (T + 1)]
+    phi = [[np.array([0.7, 0.3]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(2)]
+    bp = M.mpbp_infinite_bipartite_graph(k, w, (2, 2), phi, max_bond=8)
+    obp = O.mpbp_infinite_bipartite_graph(k, ow, (2, 2), phi)
+    M.iterate(bp, maxiter=15, svd_trunc=M.TruncBond(8), tol=0.0, schedule="sequential", shuffle_nodes=False)
+    O.iterate(obp, maxiter=15, svd_trunc=OT.TruncBond(8), tol=0.0, shuffle_nodes=False)
+    assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL
+    assert abs(M.bethe_free_energy(bp) - O.bethe_free_energy(obp)) < RTOL * max(1.0, abs(O.bethe_free_energy(obp)))
