@@ -131,21 +131,24 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     const int a = LB1(t), an = LB1(t + 1), b = LB2(t), bn = LB2(t + 1);
     const int Bm = a * b, Bn = an * bn;
     const int r1 = rdim[t + 1];
-    const double* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;    // [Bn x r1], ld Bn
+    const double* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;    // Lf^T: [r1 x Bn], ld r1 (rank index fastest)
     stage_core(A1c, P.A1, P.bond1, P.stride1, L, t, mirror, ny1 * q);
     stage_core(A2c, P.A2, P.bond2, P.stride2, L, t, mirror, ny2 * q);
     __syncthreads();
     build_E(E, A2c, P.pyy + (int64_t)TP(t) * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
     __syncthreads();
     PROF(PH_STAGE);
-    // Y1: Z[(m1,y1,xi) ; (n2,k)] = sum_n1 A1[m1,n1,y1,xi] Lf1[(n1,n2),k]
+    // Every tile index below has the rank index k fastest, so loads and stores are contiguous along k.
+    // Y1: Z[(k,n2) ; (m1,y1,xi)] = sum_n1 A1[m1,n1,y1,xi] Lf[(n1,n2),k]      Z[j + r1*bn*i], j = k + r1*n2
     const int M1 = a * ny1 * q;
-    gemm(M1, bn * r1, an, A1c,
+    const int64_t zld = (int64_t)r1 * bn;
+    gemm_direct(M1, r1 * bn, an, A1c,
          [=](int i) { return (i % a) + a * an * (i / a); }, [=](int kk) { return a * kk; },
-         Lf1, [=](int kk) { return kk; }, [=](int j) { return (int64_t)an * j; }, true,
-         Z, [=](int i) { return i; }, [=](int j) { return (int64_t)M1 * j; }, false, ldsG);
+         Lf1, [=](int kk) { return (int64_t)r1 * kk; },
+         [=](int j) { return (int64_t)(j % r1) + (int64_t)r1 * an * (j / r1); },
+         Z, [=](int i) { return zld * i; }, [=](int j) { return (int64_t)j; }, false);
     PROF(PH_Y1);
-    // Y2 (per xi): Y[(k,y,xi) ; (m1,m2)] = sum_(n2,y1) E_xi[(m2,y),(n2,y1)] Z[(m1,y1,xi),(n2,k)]
+    // Y2 (per xi): Y[(k,y,xi) ; (m1,m2)] = sum_(n2,y1) E_xi[(m2,y),(n2,y1)] Z[(k,n2),(m1,y1,xi)]
     const int rowsY = r1 * ny * q;
     const int ldY = r32(rowsY);
     const int cols16 = r16(Bm) + 16;
@@ -158,29 +161,33 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
       Y[(int64_t)ldY * Bm + idx] = 0.0;
     const int M2 = b * ny, K2 = bn * ny1;
     for (int xi = 0; xi < q; xi++) {
-      gemm(M2, a * r1, K2, E + (int64_t)xi * M2 * K2,
+      gemm_direct(M2, r1 * a, K2, E + (int64_t)xi * M2 * K2,
            [=](int i) { return i; }, [=](int kk) { return M2 * kk; },
-           Z + a * ny1 * xi, [=](int kk) { return (int64_t)a * (kk / bn) + (int64_t)M1 * (kk % bn); },
-           [=](int j) { return (int64_t)(j % a) + (int64_t)M1 * bn * (j / a); }, false,
+           Z + zld * a * ny1 * xi,
+           [=](int kk) { return (int64_t)r1 * (kk % bn) + zld * a * (kk / bn); },
+           [=](int j) { return (int64_t)(j % r1) + zld * (j / r1); },
            Y + (int64_t)r1 * ny * xi,
            [=](int i) { return (int64_t)r1 * (i / b) + (int64_t)ldY * a * (i % b); },
-           [=](int j) { return (int64_t)(j / a) + (int64_t)ldY * (j % a); }, false, ldsG);
+           [=](int j) { return (int64_t)(j % r1) + (int64_t)ldY * (j / r1); }, false);
     }
     PROF(PH_Y2);
     qr_r(Y, ldY, rowsY, Bm, ldsQ, ldsG, pr, &plast, PH_QR1_PANEL, PH_QR1_TRAIL);
     const int kmax = min(rowsY, Bm);
-    // scale = max |R| over the upper trapezoid
+    // scale = max |R| over the upper trapezoid; Lf^T = R / scale  (column loops: no integer division)
+    const int lane_ = tid & 63, wave_ = tid >> 6;
     double mx = 0.0;
-    for (int64_t idx = tid; idx < (int64_t)kmax * Bm; idx += WG_THREADS) {
-      int k = (int)(idx % kmax); int m = (int)(idx / kmax);
-      if (m >= k) mx = fmax(mx, fabs(Y[k + (int64_t)ldY * m]));
+    for (int m = wave_; m < Bm; m += WG_WAVES) {
+      const double* yc = Y + (int64_t)ldY * m;
+      const int kend = min(kmax, m + 1);
+      for (int k = lane_; k < kend; k += 64) mx = fmax(mx, fabs(yc[k]));
     }
     mx = wg_max(mx, red);
     const double inv = (mx > 0.0 && isfinite(mx)) ? 1.0 / mx : 1.0;
-    double* Lf0 = LfS + (int64_t)t * cfg.lf_stride;                 // [Bm x kmax], ld Bm
-    for (int64_t idx = tid; idx < (int64_t)kmax * Bm; idx += WG_THREADS) {
-      int m = (int)(idx % Bm); int k = (int)(idx / Bm);
-      Lf0[m + (int64_t)Bm * k] = (m >= k) ? Y[k + (int64_t)ldY * m] * inv : 0.0;
+    double* Lf0 = LfS + (int64_t)t * cfg.lf_stride;                 // Lf^T = R: [kmax x Bm], ld kmax
+    for (int m = wave_; m < Bm; m += WG_WAVES) {
+      const double* yc = Y + (int64_t)ldY * m;
+      double* lc = Lf0 + (int64_t)kmax * m;
+      for (int k = lane_; k < kmax; k += 64) lc[k] = (k <= m) ? yc[k] * inv : 0.0;
     }
     if (tid == 0) rdim[t] = kmax;
     __syncthreads();
@@ -203,25 +210,27 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     build_E(E, A2c, P.pyy + (int64_t)tp * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
     __syncthreads();
     PROF(PH_STAGE);
-    // N1: T1[(n1,y1,xi) ; (k,m2)] = sum_m1 A1[m1,n1,y1,xi] C[k,(m1,m2)]
+    // N1: T1[(k,m2) ; (n1,y1,xi)] = sum_m1 A1[m1,n1,y1,xi] C[k,(m1,m2)]        T1[j + kc*b*i], j = k + kc*m2
     const int MT1 = an * ny1 * q;
-    gemm(MT1, kc * b, a, A1c,
+    const int64_t tld = (int64_t)kc * b;
+    gemm_direct(MT1, kc * b, a, A1c,
          [=](int i) { return a * (i % an) + a * an * (i / an); }, [=](int kk) { return kk; },
          Ccur, [=](int kk) { return (int64_t)kc * kk; },
-         [=](int j) { return (int64_t)(j % kc) + (int64_t)kc * a * (j / kc); }, false,
-         T1, [=](int i) { return i; }, [=](int j) { return (int64_t)MT1 * j; }, false, ldsG);
-    // N2 (per xi): Nt[(k,y,xi) ; (n1,n2)] = sum_(m2,y1) E_xi[(m2,y),(n2,y1)] T1[(n1,y1,xi),(k,m2)]
+         [=](int j) { return (int64_t)(j % kc) + (int64_t)kc * a * (j / kc); },
+         T1, [=](int i) { return tld * i; }, [=](int j) { return (int64_t)j; }, false);
+    // N2 (per xi): Nt[(k,y,xi) ; (n1,n2)] = sum_(m2,y1) E_xi[(m2,y),(n2,y1)] T1[(k,m2),(n1,y1,xi)]
     const int Rr = kc * ny * q;
     const int M2 = b * ny, K2 = bn * ny1;
     for (int xi = 0; xi < q; xi++) {
-      gemm(bn * ny, an * kc, b * ny1, E + (int64_t)xi * M2 * K2,
+      gemm_direct(bn * ny, kc * an, b * ny1, E + (int64_t)xi * M2 * K2,
            [=](int i) { return b * (i / bn) + M2 * (i % bn); },
            [=](int kk) { return (kk % b) + M2 * bn * (kk / b); },
-           T1 + an * ny1 * xi, [=](int kk) { return (int64_t)an * (kk / b) + (int64_t)MT1 * kc * (kk % b); },
-           [=](int j) { return (int64_t)(j % an) + (int64_t)MT1 * (j / an); }, false,
+           T1 + tld * an * ny1 * xi,
+           [=](int kk) { return (int64_t)kc * (kk % b) + tld * an * (kk / b); },
+           [=](int j) { return (int64_t)(j % kc) + tld * (j / kc); },
            Nt + (int64_t)kc * ny * xi,
            [=](int i) { return (int64_t)kc * (i / bn) + (int64_t)Rr * an * (i % bn); },
-           [=](int j) { return (int64_t)(j / an) + (int64_t)Rr * (j % an); }, false, ldsG);
+           [=](int j) { return (int64_t)(j % kc) + (int64_t)Rr * (j / kc); }, false);
     }
     // rescale by max-abs (the reference rescales M at every step into z)
     {
@@ -256,7 +265,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
       Mt[rr + (int64_t)ldM * c] = 0.0;
     }
     for (int64_t idx = tid; idx < (int64_t)ldM * (Rr16 - Rr); idx += WG_THREADS) Mt[(int64_t)ldM * Rr + idx] = 0.0;
-    gemm(r1, Rr, Bn, Lf1, [=](int i) { return (int64_t)Bn * i; }, [=](int kk) { return kk; },
+    gemm(r1, Rr, Bn, Lf1, [=](int i) { return (int64_t)i; }, [=](int kk) { return (int64_t)r1 * kk; },
          Nt, [=](int kk) { return (int64_t)Rr * kk; }, [=](int j) { return j; }, false,
          Mt, [=](int i) { return i; }, [=](int j) { return (int64_t)ldM * j; }, false, ldsG);
     PROF(PH_MT);
@@ -276,7 +285,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     }
     fro2 = wg_sum(fro2, red);
     __syncthreads();
-    int sw = jacobi_rsv(JA, ldJ, Rr, k2, nullptr, 0, red, 60);
+    int sw = jacobi_rsv(JA, ldJ, Rr, k2, nullptr, 0, red, ord, 60);
     if (tid == 0) {
       if (sw < 0) stats->jacobi_fail = 1;
       atomicAdd(&stats->jac_sweeps, (unsigned long long)(sw < 0 ? 60 : sw));
@@ -341,9 +350,9 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     if (tid == 0) P.obond[mirror ? (L - (t + 1)) : (t + 1)] = kp;
     PROF(PH_TRUNC);
     // carry C' [kp x Bn] = U^T Nt
-    gemm(kp, Bn, Rr, JA, [=](int i) { return (int64_t)ldJ * ord[i]; }, [=](int kk) { return kk; },
-         Nt, [=](int kk) { return kk; }, [=](int j) { return (int64_t)Rr * j; }, true,
-         Cnew, [=](int i) { return i; }, [=](int j) { return (int64_t)kp * j; }, false, ldsG);
+    gemm_direct(kp, Bn, Rr, JA, [=](int i) { return (int64_t)ldJ * ord[i]; }, [=](int kk) { return kk; },
+         Nt, [=](int kk) { return kk; }, [=](int j) { return (int64_t)Rr * j; },
+         Cnew, [=](int i) { return i; }, [=](int j) { return (int64_t)kp * j; }, false);
     double* tmp = Ccur; Ccur = Cnew; Cnew = tmp;
     kc = kp;
     PROF(PH_CARRY);

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(WG_THREADS) st_qr_kernel(double* Y, int ld, in
 }
 __global__ void __launch_bounds__(WG_THREADS) st_svd_kernel(double* A, int m, int n, double* V, double* sigma, int* sweeps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  int sw = wg::jacobi_rsv(A, m, m, n, V, n, lds, 60);
+  int sw = wg::jacobi_rsv(A, m, m, n, V, n, lds, reinterpret_cast<int*>(lds + 32), 60);
   for (int c = threadIdx.x; c < n; c += WG_THREADS) {
     double s = 0.0;
     for (int r = 0; r < m; r++) s += A[r + (int64_t)m * c] * A[r + (int64_t)m * c];

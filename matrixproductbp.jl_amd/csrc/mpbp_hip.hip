@@ -930,7 +930,7 @@ extern "C" int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, con
   STCHK(hipMalloc(&dA, sizeof(double) * rows * cols)); STCHK(hipMalloc(&dV, sizeof(double) * cols * cols));
   STCHK(hipMalloc(&dS, sizeof(double) * cols)); STCHK(hipMalloc(&dW, sizeof(int)));
   STCHK(hipMemcpy(dA, A, sizeof(double) * rows * cols, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(st_svd_kernel, dim3(1), dim3(WG_THREADS), 64 * 8, 0, dA, rows, cols, dV, dS, dW);
+  hipLaunchKernelGGL(st_svd_kernel, dim3(1), dim3(WG_THREADS), (64 + cols) * 8, 0, dA, rows, cols, dV, dS, dW);
   STCHK(hipGetLastError()); STCHK(hipDeviceSynchronize());
   STCHK(hipMemcpy(sigma, dS, sizeof(double) * cols, hipMemcpyDeviceToHost));
   STCHK(hipMemcpy(V, dV, sizeof(double) * cols * cols, hipMemcpyDeviceToHost));

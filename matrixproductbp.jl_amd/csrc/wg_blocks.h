@@ -165,6 +165,85 @@ __device__ void gemm(int M, int N, int K, const double* Sp, SRO sro, SCO sco, co
   __syncthreads();
 }
 
+// Barrier-free variant for contractions whose M-side operand is small or cache resident (cores / coupling
+// tables in LDS, triangular factors in L2): every wave owns whole 16-column tiles of the output, takes its B
+// fragments straight from global memory (8 B per lane per k-step, all k-steps of a tile in flight together)
+// and its A fragments from wherever S lives.  No LDS staging, no __syncthreads() inside; waves never wait for
+// each other.  Same index-map interface as gemm().  Ends with a __syncthreads().
+template <class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
+__device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, const double* Sp, SRO sro, SCO sco,
+                                                     const double* Xp, XRO xro, XCO xco, double* Op, ORO oro, OCO oco,
+                                                     bool accumulate) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nks = (K + 3) >> 2;
+  const int ntile = (N + 15) >> 4;
+  for (int mb = 0; mb < M; mb += GM_MB) {
+    const int mrows = min(GM_MB, M - mb);
+    const int ntm = (mrows + 15) >> 4;
+    long s_ro[6];
+    bool s_in[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      const int i = t * 16 + l15;
+      s_in[t] = t < ntm && i < mrows;
+      s_ro[t] = s_in[t] ? (long)sro(mb + i) : 0;
+    }
+    for (int tl = wave; tl < ntile; tl += WG_WAVES) {
+      const int j = tl * 16 + l15;
+      const bool jin = j < N;
+      const long cofs = jin ? (long)xco(j) : 0;
+      d4 acc[6];
+#pragma unroll
+      for (int t = 0; t < 6; t++) acc[t] = d4{0, 0, 0, 0};
+      for (int ks0 = 0; ks0 < nks; ks0 += 5) {
+        double b[5];
+        long so[5];
+        bool kin[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          const int k = 4 * (ks0 + u) + g;
+          kin[u] = (ks0 + u < nks) && k < K;
+          const int kc = kin[u] ? k : 0;
+          b[u] = Xp[(long)xro(kc) + cofs];          // unconditional load (valid address), masked below
+          so[u] = (long)sco(kc);
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          const double bv = (kin[u] && jin) ? b[u] : 0.0;
+#pragma unroll
+          for (int t = 0; t < 6; t++) {
+            if (t < ntm) {
+              const double a = (s_in[t] && kin[u]) ? Sp[s_ro[t] + so[u]] : 0.0;
+              acc[t] = mfma(a, bv, acc[t]);
+            }
+          }
+        }
+      }
+      if (jin) {
+        const long oc = (long)oco(j);
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+          if (t < ntm) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int row = t * 16 + g + 4 * r;
+              if (row < mrows) {
+                double* p = Op + (long)oro(mb + row) + oc;
+                double v = acc[t][r];
+                if (accumulate) v += *p;
+                *p = v;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // workgroup reductions through LDS (red must hold WG_WAVES*NV doubles)
 // ---------------------------------------------------------------------------------------------
@@ -834,12 +913,14 @@ __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double
 // One-sided Jacobi (Hestenes): A (m x n, ld lda) -> A V = U Sigma; V (n x n, ld ldv) accumulated from I
 // (V == nullptr: not accumulated - the rotated columns sigma_j u_j then carry the LEFT singular vectors).
 // Column norms of the final A are the singular values (unsorted).  8 lanes per column pair.
-// Returns number of sweeps used (all threads), or -1 if not converged in maxsweeps.
-// n is padded to even internally via a virtual zero column (skipped).  `red`: >= 16 doubles.
-// A and V may live in LDS or global memory (generic pointers).
+// Deflation: a column whose norm falls below 1e-14 ||A||_F is numerically null; it only carries rounding
+// noise, rotating it never converges and never matters, and it can never grow back - after every sweep the
+// null columns leave the tournament, so later sweeps run over the active columns only.
+// `red`: >= 16 doubles; `act`: >= n ints of LDS.  Returns the number of sweeps, or -1 if not converged.
+// lda / ldv should be odd (LDS bank spreading between the column pairs of different lane groups).
 // ---------------------------------------------------------------------------------------------
-__device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, double* red, int maxsweeps) {
-  // lda / ldv should be odd (LDS bank spreading between the column pairs of different lane groups)
+__device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, double* red, int* act,
+                          int maxsweeps) {
   const int tid = threadIdx.x;
   if (V) {
     for (int idx = tid; idx < n * n; idx += WG_THREADS) {
@@ -847,22 +928,22 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
       V[r + (long)ldv * c] = (r == c) ? 1.0 : 0.0;
     }
   }
+  for (int c = tid; c < n; c += WG_THREADS) act[c] = c;
   __syncthreads();
   if (n < 2) return 0;
-  // columns whose norm falls below 1e-14 ||A||_F are numerically null (they only carry the rounding noise
-  // of the preceding QR); rotating them against anything never converges and never matters
   double fro2 = 0.0;
   for (int idx = tid; idx < m * n; idx += WG_THREADS) { double v = A[(idx % m) + (long)lda * (idx / m)]; fro2 += v * v; }
   fro2 = wg_sum(fro2, red);
   const double nul = 1e-28 * fro2;
-  const int ne = (n + 1) & ~1;          // even number of "players"
-  const int npairs = ne / 2;
   const int sub = tid & 7;              // lane inside the 8-lane pair group
   const int grp = tid >> 3;             // 64 groups per pass
   const double tol = 1e-15;
+  int nact = n;
   int sweep = 0;
   bool conv = false;
   for (; sweep < maxsweeps; sweep++) {
+    const int ne = (nact + 1) & ~1;       // even number of "players"
+    const int npairs = ne / 2;
     int rotated = 0;
     for (int round = 0; round < ne - 1; round++) {
       for (int pb = 0; pb < npairs; pb += WG_THREADS / 8) {
@@ -876,9 +957,10 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
             q = (round + (ne - 1) - pi) % (ne - 1);
           }
           if (p > q) { int t_ = p; p = q; q = t_; }
-          if (q < n) {
-            double* ap = A + (long)lda * p;
-            double* aq = A + (long)lda * q;
+          if (q < nact) {
+            const int cp = act[p], cq = act[q];
+            double* ap = A + (long)lda * cp;
+            double* aq = A + (long)lda * cq;
             double al = 0, be = 0, ga = 0;
             for (int r = sub; r < m; r += 8) { double x = ap[r], y = aq[r]; al += x * x; be += y * y; ga += x * y; }
 #pragma unroll
@@ -893,8 +975,8 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
               const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
               for (int r = sub; r < m; r += 8) { double x = ap[r], y = aq[r]; ap[r] = c * x - s * y; aq[r] = s * x + c * y; }
               if (V) {
-                double* vp = V + (long)ldv * p;
-                double* vq = V + (long)ldv * q;
+                double* vp = V + (long)ldv * cp;
+                double* vq = V + (long)ldv * cq;
                 for (int r = sub; r < n; r += 8) { double x = vp[r], y = vq[r]; vp[r] = c * x - s * y; vq[r] = s * x + c * y; }
               }
             }
@@ -906,6 +988,27 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
     // converged if nobody rotated in this sweep
     double any = wg_max((double)rotated, red);
     if (any == 0.0) { conv = true; break; }
+    // deflate: one thread per active column measures it, thread 0 compacts the list
+    int keep = 0, mycol = -1;
+    if (tid < nact) {
+      mycol = act[tid];
+      const double* ac = A + (long)lda * mycol;
+      double s2 = 0.0;
+      for (int r = 0; r < m; r++) s2 += ac[r] * ac[r];
+      keep = s2 > nul;
+    }
+    __syncthreads();
+    if (tid < nact) act[tid] = keep ? mycol : -1;
+    __syncthreads();
+    if (tid == 0) {
+      int w = 0;
+      for (int i = 0; i < nact; i++) { const int c = act[i]; if (c >= 0) act[w++] = c; }
+      red[15] = (double)w;
+    }
+    __syncthreads();
+    nact = (int)red[15];
+    __syncthreads();
+    if (nact < 2) { conv = true; break; }
   }
   __syncthreads();
   return conv ? sweep + 1 : -1;
