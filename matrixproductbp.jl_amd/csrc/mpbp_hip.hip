@@ -887,7 +887,7 @@ extern "C" int mpbp_selftest_qr(int32_t device, int32_t rows, int32_t cols, cons
   double* dY;
   STCHK(hipMalloc(&dY, sizeof(double) * Y.size()));
   STCHK(hipMemcpy(dY, Y.data(), sizeof(double) * Y.size(), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 256) * 8, 0, dY, ld, rows, cols);
+  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 512) * 8, 0, dY, ld, rows, cols);
   STCHK(hipGetLastError()); STCHK(hipDeviceSynchronize());
   STCHK(hipMemcpy(Y.data(), dY, sizeof(double) * Y.size(), hipMemcpyDeviceToHost));
   const int k = std::min(rows, cols);
@@ -913,7 +913,7 @@ extern "C" int mpbp_selftest_qr_bench(int32_t device, int32_t rows, int32_t cols
     for (int b = 0; b < nblocks; b++) STCHK(hipMemcpyAsync(dY + per * b, dY0, sizeof(double) * per, hipMemcpyDeviceToDevice, 0));
     STCHK(hipDeviceSynchronize());
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(st_qr_kernel, dim3(nblocks), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 256) * 8, 0, dY, ld, rows, cols);
+    hipLaunchKernelGGL(st_qr_kernel, dim3(nblocks), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 512) * 8, 0, dY, ld, rows, cols);
     hipEventRecord(e1, 0);
     STCHK(hipEventSynchronize(e1));
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);

@@ -344,12 +344,125 @@ __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane, in
   return a1;
 }
 
-// register-resident panel factorisation (rows - j0 <= QR_RS * WG_THREADS).  The active column is always
-// register column 0 (finished columns are stored and the register panel is shifted), so every register
-// index is a compile-time constant.  T is NOT built here (see qr_build_T).
+// 8 per-lane partial values -> lanes with (lane & 7) == 0 hold the wave total of value
+// idx = ((lane>>5)&1)<<2 | ((lane>>4)&1)<<1 | ((lane>>3)&1)
+__device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane, int& idx) {
+  double a4[4], a2[2], a1;
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double keep = b5 ? v[i + 4] : v[i], send = b5 ? v[i] : v[i + 4];
+    a4[i] = keep + __shfl_xor(send, 32, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    double keep = b4 ? a4[i + 2] : a4[i], send = b4 ? a4[i] : a4[i + 2];
+    a2[i] = keep + __shfl_xor(send, 16, 64);
+  }
+  {
+    double keep = b3 ? a2[1] : a2[0], send = b3 ? a2[0] : a2[1];
+    a1 = keep + __shfl_xor(send, 8, 64);
+  }
+  a1 += __shfl_xor(a1, 4, 64);
+  a1 += __shfl_xor(a1, 2, 64);
+  a1 += __shfl_xor(a1, 1, 64);
+  idx = (b5 ? 4 : 0) | (b4 ? 2 : 0) | (b3 ? 1 : 0);
+  return a1;
+}
+
+// One column step of the register panel with the column index JJ a compile-time constant: only the
+// columns c >= JJ are touched (half the work of a fixed 16-wide step, no register shifting).
+template <int JJ>
+__device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const bool (&rv)[QR_RS], double* Y, long ld,
+                                              int j0, double* red, double* tau, double* tot, double* rowb) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* totj = tot + 16 * (JJ & 1);
+  double* rowj = rowb + 16 * (JJ & 1);
+  constexpr int NV = QR_NB - JJ;           // values to reduce: |x|^2 and NV-1 dots
+  if (NV > 8) {
+    double vals[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) vals[c] = 0.0;
+#pragma unroll
+    for (int s = 0; s < QR_RS; s++) {
+      const bool below = rv[s] && (s > 0 || tid > JJ);
+      const double x = below ? P[s][JJ] : 0.0;
+#pragma unroll
+      for (int c = JJ; c < QR_NB; c++) vals[c - JJ] += x * P[s][c];
+    }
+    int idx;
+    const double wsum = wave_sum16(vals, lane, idx);
+    if ((lane & 3) == 0) red[wave * 16 + idx] = wsum;
+  } else {
+    double vals[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) vals[c] = 0.0;
+#pragma unroll
+    for (int s = 0; s < QR_RS; s++) {
+      const bool below = rv[s] && (s > 0 || tid > JJ);
+      const double x = below ? P[s][JJ] : 0.0;
+#pragma unroll
+      for (int c = JJ; c < QR_NB; c++) vals[c - JJ] += x * P[s][c];
+    }
+    int idx;
+    const double wsum = wave_sum8(vals, lane, idx);
+    if ((lane & 7) == 0) red[wave * 16 + idx] = wsum;
+  }
+  if (tid == JJ) {
+#pragma unroll
+    for (int c = JJ; c < QR_NB; c++) rowj[c - JJ] = P[0][c];
+  }
+  __syncthreads();
+  if (tid < NV) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int w = 0; w < WG_WAVES; w++) sacc += red[w * 16 + tid];
+    totj[tid] = sacc;
+  }
+  __syncthreads();
+  const double ss = totj[0];
+  const double alpha = rowj[0];
+  double beta, tj, scale;
+  if (ss == 0.0) { beta = alpha; tj = 0.0; scale = 0.0; }
+  else {
+    beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+    tj = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  if (tid == 0) tau[JJ] = tj;
+  double tw[QR_NB];
+#pragma unroll
+  for (int c = JJ + 1; c < QR_NB; c++) tw[c] = tj * (rowj[c - JJ] + scale * totj[c - JJ]);
+#pragma unroll
+  for (int s = 0; s < QR_RS; s++) {
+    const bool below = rv[s] && (s > 0 || tid > JJ);
+    const bool pivot = (s == 0) && (tid == JJ);
+    const double v = below ? P[s][JJ] * scale : (pivot ? 1.0 : 0.0);
+    if (below) P[s][JJ] = v;
+    if (pivot) P[s][JJ] = beta;
+#pragma unroll
+    for (int c = JJ + 1; c < QR_NB; c++) P[s][c] -= tw[c] * v;
+  }
+  const long coff = (long)(j0 + JJ) * ld;
+#pragma unroll
+  for (int s = 0; s < QR_RS; s++)
+    if (rv[s]) Y[coff + j0 + tid + WG_THREADS * s] = P[s][JJ];
+}
+
+template <int JJ>
+__device__ __forceinline__ void qr_panel_steps(double (&P)[QR_RS][QR_NB], const bool (&rv)[QR_RS], double* Y, long ld,
+                                               int j0, int nb, double* red, double* tau, double* tot, double* rowb) {
+  if constexpr (JJ < QR_NB) {
+    if (JJ < nb) qr_panel_step<JJ>(P, rv, Y, ld, j0, red, tau, tot, rowb);
+    qr_panel_steps<JJ + 1>(P, rv, Y, ld, j0, nb, red, tau, tot, rowb);
+  }
+}
+
+// register-resident panel factorisation (rows - j0 <= QR_RS * WG_THREADS); T is built afterwards from the
+// Gram matrix of V (qr_gram + qr_T_from_gram).
 __device__ __attribute__((noinline)) void qr_panel_regs(double* Y, long ld, int rows, int j0, int nb, double* red,
                                               double* tau, double* bc) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   double P[QR_RS][QR_NB];
   bool rv[QR_RS];
 #pragma unroll
@@ -361,107 +474,70 @@ __device__ __attribute__((noinline)) void qr_panel_regs(double* Y, long ld, int 
   }
   double* tot = bc;            // [2][16] wave-summed totals (double buffered by column parity)
   double* rowb = bc + 32;      // [2][16] the pivot row of the panel
-  for (int jj = 0; jj < nb; jj++) {
-    double* totj = tot + 16 * (jj & 1);
-    double* rowj = rowb + 16 * (jj & 1);
-    // partial |x|^2 (c = 0) and dots with the remaining columns over the rows strictly below the pivot row
-    double vals[16];
-#pragma unroll
-    for (int c = 0; c < QR_NB; c++) vals[c] = 0.0;
-#pragma unroll
-    for (int s = 0; s < QR_RS; s++) {
-      const bool below = rv[s] && (s > 0 || tid > jj);
-      const double x = below ? P[s][0] : 0.0;
-#pragma unroll
-      for (int c = 0; c < QR_NB; c++) vals[c] += x * P[s][c];
-    }
-    int idx;
-    const double wsum = wave_sum16(vals, lane, idx);
-    if ((lane & 3) == 0) red[wave * 16 + idx] = wsum;
-    if (tid == jj) {
-#pragma unroll
-      for (int c = 0; c < QR_NB; c++) rowj[c] = P[0][c];
-    }
-    __syncthreads();
-    if (tid < 16) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int w = 0; w < WG_WAVES; w++) sacc += red[w * 16 + tid];
-      totj[tid] = sacc;
-    }
-    __syncthreads();
-    const double ss = totj[0];
-    const double alpha = rowj[0];
-    double beta, tj, scale;
-    if (ss == 0.0) { beta = alpha; tj = 0.0; scale = 0.0; }
-    else {
-      beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-      tj = (beta - alpha) / beta;
-      scale = 1.0 / (alpha - beta);
-    }
-    if (tid == 0) tau[jj] = tj;
-    // update the registers: w_c = row term + scale * dot
-#pragma unroll
-    for (int s = 0; s < QR_RS; s++) {
-      const bool below = rv[s] && (s > 0 || tid > jj);
-      const bool pivot = (s == 0) && (tid == jj);
-      const double v = below ? P[s][0] * scale : (pivot ? 1.0 : 0.0);
-      if (below) P[s][0] = v;
-      if (pivot) P[s][0] = beta;
-#pragma unroll
-      for (int c = 1; c < QR_NB; c++) P[s][c] -= (tj * (rowj[c] + scale * totj[c])) * v;
-    }
-    // store the finished column and shift the register panel
-    const long coff = (long)(j0 + jj) * ld;
-#pragma unroll
-    for (int s = 0; s < QR_RS; s++) {
-      if (rv[s]) Y[coff + j0 + tid + WG_THREADS * s] = P[s][0];
-#pragma unroll
-      for (int c = 0; c < QR_NB - 1; c++) P[s][c] = P[s][c + 1];
-      P[s][QR_NB - 1] = 0.0;
-    }
-  }
+  qr_panel_steps<0>(P, rv, Y, ld, j0, nb, red, tau, tot, rowb);
   __syncthreads();
 }
 
-// G[i + 16 j] = sum_r Vx[r][i] Vy[r][j] over the rows from `jrow` (a multiple of 16) by MFMA: every wave takes
-// the row blocks rb = wave, wave+8, ...; partials are reduced through `big` (>= WG_WAVES*256 doubles of LDS).
-// Vx / Vy are panels stored in place (unit lower-trapezoidal heads at column offsets jx / jy, nbx / nby
-// reflectors).  Result in big[0..255]; ends with a barrier.
+// G1[i + 16 j] = sum_r Vx[r][i] Vy[r][j]  and (if TWO) G2[i + 16 j] = sum_r Vx[r][i] Vz[r][j]  over the rows
+// from `jrow` (a multiple of 16) by MFMA: every wave takes the row blocks rb = wave, wave+8, ... with the loads
+// of the next block in flight; partials are reduced through `big` (>= WG_WAVES*512 doubles of LDS).
+// Vx / Vy / Vz are panels stored in place (unit lower-trapezoidal heads at column offsets jx / jy / jz with
+// nbx / nby / nbz reflectors).  Results in big[0..255] and big[256..511]; ends with a barrier.
+template <bool TWO>
 __device__ __forceinline__ void qr_gram(const double* Y, long ld, int rows32, int jrow, int jx, int nbx, int jy,
-                                        int nby, double* big) {
+                                        int nby, int jz, int nbz, double* big) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - jrow) >> 4;
   const double* xcol = Y + (long)(jx + l15) * ld + jrow + 4 * g;
   const double* ycol = Y + (long)(jy + l15) * ld + jrow + 4 * g;
-  d4 acc = d4{0, 0, 0, 0};
-  for (int rb = wave; rb < nrb; rb += WG_WAVES) {
-    d4 vx = *reinterpret_cast<const d4*>(xcol + 16 * rb);
-    d4 vy = *reinterpret_cast<const d4*>(ycol + 16 * rb);
+  const double* zcol = Y + (long)(jz + l15) * ld + jrow + 4 * g;
+  d4 acc1 = d4{0, 0, 0, 0}, acc2 = d4{0, 0, 0, 0};
+  auto head = [&](d4& v, int rb, int jv, int nbv) {
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const int row = jrow + 16 * rb + 4 * g + e;
-      const int rx = row - jx, ry = row - jy;       // relative to each panel's diagonal block
-      double a = vx[e], b = vy[e];
-      a = (rx < 16) ? ((rx > l15) ? a : ((rx == l15) ? 1.0 : 0.0)) : a;
-      b = (ry < 16) ? ((ry > l15) ? b : ((ry == l15) ? 1.0 : 0.0)) : b;
-      vx[e] = (l15 < nbx && rx >= 0) ? a : 0.0;
-      vy[e] = (l15 < nby && ry >= 0) ? b : 0.0;
+      const int rr = jrow + 16 * rb + 4 * g + e - jv;       // relative to the panel's diagonal block
+      double a = v[e];
+      a = (rr < 16) ? ((rr > l15) ? a : ((rr == l15) ? 1.0 : 0.0)) : a;
+      v[e] = (l15 < nbv && rr >= 0 && rb < nrb) ? a : 0.0;
     }
+  };
+  d4 vx[2], vy[2], vz[2];
+  auto load = [&](int rb, d4& a, d4& b, d4& c) {
+    const int rbc = min(rb, nrb - 1);
+    a = *reinterpret_cast<const d4*>(xcol + 16 * rbc);
+    b = *reinterpret_cast<const d4*>(ycol + 16 * rbc);
+    if (TWO) c = *reinterpret_cast<const d4*>(zcol + 16 * rbc);
+  };
+  auto comp = [&](int rb, d4& a, d4& b, d4& c) {
+    head(a, rb, jx, nbx); head(b, rb, jy, nby);
+    if (TWO) head(c, rb, jz, nbz);
 #pragma unroll
-    for (int e = 0; e < 4; e++) acc = mfma(vx[e], vy[e], acc);
+    for (int e = 0; e < 4; e++) {
+      acc1 = mfma(a[e], b[e], acc1);
+      if (TWO) acc2 = mfma(a[e], c[e], acc2);
+    }
+  };
+  if (wave < nrb) load(wave, vx[0], vy[0], vz[0]);
+  for (int rb = wave; rb < nrb; rb += 2 * WG_WAVES) {
+    load(rb + WG_WAVES, vx[1], vy[1], vz[1]);
+    comp(rb, vx[0], vy[0], vz[0]);
+    load(rb + 2 * WG_WAVES, vx[0], vy[0], vz[0]);
+    comp(rb + WG_WAVES, vx[1], vy[1], vz[1]);
   }
 #pragma unroll
-  for (int r = 0; r < 4; r++) big[wave * 256 + (g + 4 * r) + 16 * l15] = acc[r];
-  __syncthreads();
-  double sacc = 0.0;
-  if (tid < 256) {
-#pragma unroll
-    for (int w = 0; w < WG_WAVES; w++) sacc += big[w * 256 + tid];
+  for (int r = 0; r < 4; r++) {
+    big[wave * 512 + (g + 4 * r) + 16 * l15] = acc1[r];
+    if (TWO) big[wave * 512 + 256 + (g + 4 * r) + 16 * l15] = acc2[r];
   }
   __syncthreads();
-  if (tid < 256) big[tid] = sacc;
+  double s1 = 0.0;
+  if (tid < (TWO ? 512 : 256)) {
+#pragma unroll
+    for (int w = 0; w < WG_WAVES; w++) s1 += big[w * 512 + tid];
+  }
+  __syncthreads();
+  if (tid < (TWO ? 512 : 256)) big[tid] = s1;
   __syncthreads();
 }
 
@@ -836,7 +912,7 @@ __device__ __forceinline__ void qr_tile_update_all(double* Y, long ld, int rows3
   __syncthreads();
 }
 
-// `big`: >= WG_WAVES*256 doubles of LDS scratch (may alias the gemm tile buffers)
+// `big`: >= WG_WAVES*512 doubles of LDS scratch (may alias the gemm tile buffers)
 __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double* big, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -862,7 +938,7 @@ __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double
     __syncthreads();
     if (fast) {
       qr_panel_regs(Y, ld, rows, j0, nb, red, tau, bc);
-      qr_gram(Y, ld, rows32, j0, j0, nb, j0, nb, big);
+      qr_gram<false>(Y, ld, rows32, j0, j0, nb, j0, nb, j0, nb, big);
       qr_T_from_gram(big, tau, nb, Ts);
     } else qr_panel_global(Y, ld, rows, j0, nb, red, Ts, tau, bc);
     // pair with the next panel when both are full-width register panels and a trailing matrix remains
@@ -876,11 +952,9 @@ __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double
       if (tid < 16) tauB[tid] = 0.0;
       __syncthreads();
       qr_panel_regs(Y, ld, rows, j1, nbb, red, tauB, bc);
-      qr_gram(Y, ld, rows32, j1, j1, nbb, j1, nbb, big);
+      qr_gram<true>(Y, ld, rows32, j0, j1, nbb, j1, nbb, j0, 16, big);   // Vb^T Vb and S = Vb^T Va in one pass
+      if (tid < 256) Sm[tid] = big[256 + tid];
       qr_T_from_gram(big, tauB, nbb, TsB);
-      qr_gram(Y, ld, rows32, j1, j1, nbb, j0, 16, big);     // S = Vb^T Va
-      if (tid < 256) Sm[tid] = big[tid];
-      __syncthreads();
       if (pr) prof_mark(pr, *plast, ph_panel);
     }
     // ------------------------------------------------------------------ trailing update
