@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--T", type=int, default=50)
     ap.add_argument("--bond", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (gloo = rehearsal on one GPU)")
+    ap.add_argument("--dump-beliefs", default="", help="write rank-0 beliefs + f to this .npy file (parity checks)")
     ap.add_argument("--phase-profile", action="store_true", help="print the engine phase profile to stderr")
     args = ap.parse_args()
 
@@ -111,11 +113,16 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # rehearsal: several ranks may share one GPU (gloo backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- BASELINE configs[1]: SIS, 3-regular random graph
     N, T, Mb = args.nodes, args.T, args.bond
@@ -164,10 +171,23 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if args.dump_beliefs:
+        # beliefs / f of the nodes this rank owns; rank 0 gathers them
+        b = np.array(M.beliefs(bp))[lo:hi]
+        f = np.zeros(N)
+        bp._L.mpbp_free_energy(bp._h, f.ctypes.data_as(C.POINTER(C.c_double)))
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, (lo, hi, b, f[lo:hi]))
+        else:
+            parts = [(lo, hi, b, f[lo:hi])]
+        if rank == 0:
+            ball = np.concatenate([p_[2] for p_ in parts]); fall = np.concatenate([p_[3] for p_ in parts])
+            np.save(args.dump_beliefs, {"beliefs": ball, "f": fall}, allow_pickle=True)
     if rank == 0 and args.phase_profile:
         bp._L.mpbp_phase_profile(bp._h, ph.ctypes.data_as(C.POINTER(C.c_double)), 24, 0)
         names = ["stage", "Y1", "Y2", "qr1_panel", "qr1_trail", "Lf", "N", "Mt", "qr2_panel", "qr2_trail", "jacobi",

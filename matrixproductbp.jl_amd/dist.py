@@ -55,11 +55,20 @@ def slot_map(nbr_ptr, out_edge, n_edges, world):
 def allgather_slots(cores, bonds, S, rank, world, group=None):
     """One exchange step: all-gather the rank-owned slot ranges of the two slab tensors in place.
     `cores`: [world*S, slot_doubles] float64, `bonds`: [world*S, T+2] int32 (torch tensors)."""
+    import torch
     import torch.distributed as dist
     for t in (cores, bonds):
         mine = t[rank * S:(rank + 1) * S]
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(t, mine, group=group)       # in place: send = recv + rank*count
+        elif t.is_cuda:
+            # gloo rehearsal with device slabs (e.g. two ranks sharing one GPU): stage through the host
+            host = mine.cpu()
+            outs = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(outs, host, group=group)
+            for r in range(world):
+                if r != rank:
+                    t[r * S:(r + 1) * S].copy_(outs[r])
         else:
             outs = [t[r * S:(r + 1) * S] for r in range(world)]
             dist.all_gather(outs, mine.clone(), group=group)

@@ -1,0 +1,8 @@
+import ctypes as C, sys
+sys.path.insert(0, "/root/repo")
+import mpbp_amd
+L = mpbp_amd._lib.lib()
+ms = C.c_double()
+for nb in (16, 64, 128, 256):
+    L.mpbp_selftest_qr_bench(0, 1600, 400, nb, 2, C.byref(ms))
+    print(f"QR 1600x400, {nb} concurrent blocks: {ms.value:.2f} ms per launch")
