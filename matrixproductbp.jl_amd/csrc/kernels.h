@@ -97,6 +97,45 @@ __global__ void ctilde_kernel(const CtProb* probs, int L) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// compose: train of  new(x) + c * old(x)  by block-diagonal direct sum (TensorTrains `_compose`, used by the
+// damping branch of set_msg!, reference src/recursive_bp_factor.jl:172-173); both inputs have z = 1.
+// ------------------------------------------------------------------------------------------------
+struct ComposeProb {
+  const double* an; const int32_t* bn; int64_t nstride;     // new message
+  const double* ao; const int32_t* bo; int64_t ostride;     // old message (message slab)
+  double* out; int32_t* obond; int64_t outstride; double* ologz;
+  double c; int32_t p;
+};
+
+__global__ void compose_kernel(const ComposeProb* probs, int L) {
+  const ComposeProb P = probs[blockIdx.y];
+  const int t = blockIdx.x;
+  const int nl = P.bn[t], nr = P.bn[t + 1], ol = P.bo[t], orr = P.bo[t + 1];
+  const int cl = (t == 0) ? 1 : nl + ol, cr = (t == L - 1) ? 1 : nr + orr;
+  if (threadIdx.x == 0) {
+    P.obond[t] = cl;
+    if (t == L - 1) { P.obond[L] = 1; *P.ologz = 0.0; }
+  }
+  const double* A = P.an + (int64_t)t * P.nstride;
+  const double* B = P.ao + (int64_t)t * P.ostride;
+  double* O = P.out + (int64_t)t * P.outstride;
+  const int tot = cl * cr * P.p;
+  for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+    int m = idx % cl; int rest = idx / cl; int n = rest % cr; int s = rest / cr;
+    double v = 0.0;
+    if (t == 0) {
+      v = (n < nr) ? A[(int64_t)nl * (n + (int64_t)nr * s)] : P.c * B[(int64_t)ol * ((n - nr) + (int64_t)orr * s)];
+    } else if (t == L - 1) {
+      v = (m < nl) ? A[m + (int64_t)nl * nr * s] : B[(m - nl) + (int64_t)ol * orr * s];
+    } else {
+      if (m < nl && n < nr) v = A[m + (int64_t)nl * (n + (int64_t)nr * s)];
+      else if (m >= nl && n >= nr) v = B[(m - nl) + (int64_t)ol * ((n - nr) + (int64_t)orr * s)];
+    }
+    O[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // env: environment scans of an explicit train: log sum_x prod_t A_t(x_t) (normalize!, normalization),
 // per-site marginals, and the rescaled copy that becomes the stored message.
 // ------------------------------------------------------------------------------------------------

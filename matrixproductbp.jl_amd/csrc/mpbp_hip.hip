@@ -531,7 +531,6 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
   if (!c) return MPBP_EINVAL;
   if (n_nodes < 0 || (n_nodes > 0 && !nodes)) return c->fail(MPBP_EINVAL, "bad node list");
   if (!(damp >= 0.0 && damp < 1.0)) return c->fail(MPBP_EINVAL, "damp must satisfy 0 <= damp < 1 (reference src/recursive_bp_factor.jl:169)");
-  if (damp != 0.0) return c->fail(MPBP_EUNSUPPORTED, "damping (set_msg! with damp > 0) is not implemented on the device path yet");
   if (trunc.kind < 0 || trunc.kind > 3) return c->fail(MPBP_EINVAL, "unknown truncation kind %d", trunc.kind);
   if (trunc.kind != MPBP_TRUNC_THRESH && trunc.mprime < 1) return c->fail(MPBP_EINVAL, "mprime must be >= 1");
   hipSetDevice(c->device);
@@ -592,7 +591,7 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
     }
   }
   // finalisation trains: ctilde (bond 2*cap... = q*cap), engine output (message), belief ctilde
-  struct FinRec { int k, j, p, src, ct, out; };
+  struct FinRec { int k, j, p, src, ct, out; int nrm = -1, sum = -1, out2 = -1, occ = 0; };
   std::vector<FinRec> fins; std::vector<FinRec> bels;
   const int capct = q * cap;
   for (int k = 0; k < n_nodes; k++) {
@@ -602,7 +601,14 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
       const int p = c->nbr_ptr[i] + j;
       const int ct = new_train(capct, q * q, 1, 0, 0);      // explicit cores: ny = q*qj, engine q = 1
       const int out = new_train(cap, q * q, 1, 0, 0);
-      fins.push_back({k, j, p, P.dest[j], ct, out});
+      FinRec fr{k, j, p, P.dest[j], ct, out};
+      if (damp > 0.0) {
+        fr.nrm = new_train(cap, q * q, 1, 0, 0);            // normalised new message
+        fr.sum = new_train(2 * cap, q * q, 1, 0, 0);        // new + damp/(1-damp) * old  (direct sum)
+        fr.out2 = new_train(cap, q * q, 1, 0, 0);           // compressed again
+        for (int j2 = 0; j2 < j; j2++) if (c->out_edge[c->nbr_ptr[i] + j2] == c->out_edge[p]) fr.occ++;
+      }
+      fins.push_back(fr);
     }
     const int ctb = new_train(capct, q, 1, 0, 0);           // belief: qj = 1
     bels.push_back({k, -1, -1, P.full, ctb, -1});
@@ -733,7 +739,8 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
     }
     int rc = launch_engine(c, pl, trunc, false, &ms_orth, &n_orth);
     if (rc != MPBP_OK) return rc;
-    // env: normalize! the messages into the slab; beliefs marginals + log z_i
+    // env: normalize! the messages into the slab (damp = 0) or into a temporary (damp > 0);
+    //      beliefs marginals + log z_i
     std::vector<EnvProb> eps;
     size_t rv_doubles = 0;
     std::vector<size_t> rv_off;
@@ -746,7 +753,8 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
       const DevTrain& out = tr[fr.out];
       EnvProb P{};
       P.in = out.cores; P.ibond = out.bonds; P.istride = out.stride; P.ilogz = out.logz; P.p = q * q;
-      P.dst = last ? c->slot_cores(eo) : nullptr; P.dbond = last ? c->slot_bonds(eo) : nullptr; P.dstride = c->core_stride;
+      if (damp > 0.0) { const DevTrain& nm = tr[fr.nrm]; P.dst = nm.cores; P.dbond = nm.bonds; P.dstride = nm.stride; }
+      else { P.dst = last ? c->slot_cores(eo) : nullptr; P.dbond = last ? c->slot_bonds(eo) : nullptr; P.dstride = c->core_stride; }
       P.marg = nullptr; P.logz_out = c->d_logz_pos + fr.p; P.bmax = cap;
       rv_off.push_back(rv_doubles); rv_doubles += (size_t)(L + 1) * cap;
       eps.push_back(P);
@@ -762,15 +770,63 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
       eps.push_back(P);
     }
     if (capct > 256) return c->fail(MPBP_EUNSUPPORTED, "q*max_bond > 256 not supported by the scan kernels yet");
-    if (!eps.empty()) {
-      rc = ensure_arena(c, c->scratch, sizeof(EnvProb) * eps.size() + sizeof(double) * rv_doubles + 8192);
-      if (rc != MPBP_OK) return rc;
-      double* rvbase = (double*)(c->scratch.base + ((sizeof(EnvProb) * eps.size() + 255) & ~size_t(255)));
-      for (size_t s = 0; s < eps.size(); s++) eps[s].rvec = rvbase + rv_off[s];
-      HIPCHK(c, hipMemcpyAsync(c->scratch.base, eps.data(), sizeof(EnvProb) * eps.size(), hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(env_kernel, dim3((unsigned)eps.size()), dim3(256), 0, c->stream, (const EnvProb*)c->scratch.base, L);
+    auto run_env = [&](std::vector<EnvProb>& ev, const std::vector<size_t>& off, size_t rvd) -> int {
+      if (ev.empty()) return MPBP_OK;
+      int rc2 = ensure_arena(c, c->scratch, sizeof(EnvProb) * ev.size() + sizeof(double) * rvd + 8192);
+      if (rc2 != MPBP_OK) return rc2;
+      double* rvbase = (double*)(c->scratch.base + ((sizeof(EnvProb) * ev.size() + 255) & ~size_t(255)));
+      for (size_t s2 = 0; s2 < ev.size(); s2++) ev[s2].rvec = rvbase + off[s2];
+      HIPCHK(c, hipMemcpyAsync(c->scratch.base, ev.data(), sizeof(EnvProb) * ev.size(), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(env_kernel, dim3((unsigned)ev.size()), dim3(256), 0, c->stream, (const EnvProb*)c->scratch.base, L);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      return MPBP_OK;
+    };
+    rc = run_env(eps, rv_off, rv_doubles);
+    if (rc != MPBP_OK) return rc;
+    // ---- damping (reference src/recursive_bp_factor.jl:172-176): mu = compress!(new + damp/(1-damp) old), normalize!
+    if (damp > 0.0) {
+      int maxocc = 0;
+      for (const FinRec& fr : fins) maxocc = std::max(maxocc, fr.occ);
+      for (int round = 0; round <= maxocc; round++) {      // aliased out-edges compound in the reference's loop order
+        std::vector<ComposeProb> cps2; EngLaunchPlan pl2; std::vector<EnvProb> ev2; std::vector<size_t> off2; size_t rvd2 = 0;
+        pl2.q = 1; pl2.capout = cap; pl2.cap1 = 2 * cap; pl2.cap2 = 1; pl2.ny1 = q * q; pl2.ny2 = 1; pl2.ny = q * q;
+        for (const FinRec& fr : fins) {
+          if (fr.occ != round) continue;
+          const int eo = c->out_edge[fr.p];
+          const DevTrain &nm = tr[fr.nrm], &sm = tr[fr.sum], &o2 = tr[fr.out2];
+          ComposeProb CP{};
+          CP.an = nm.cores; CP.bn = nm.bonds; CP.nstride = nm.stride;
+          CP.ao = c->slot_cores(eo); CP.bo = c->slot_bonds(eo); CP.ostride = c->core_stride;
+          CP.out = sm.cores; CP.obond = sm.bonds; CP.outstride = sm.stride; CP.ologz = sm.logz;
+          CP.c = damp / (1.0 - damp); CP.p = q * q;
+          cps2.push_back(CP);
+          EngProb EP{};
+          EP.A1 = sm.cores; EP.bond1 = sm.bonds; EP.stride1 = sm.stride; EP.ny1 = q * q;
+          EP.A2 = c->d_one; EP.bond2 = c->d_ones; EP.stride2 = 0; EP.ny2 = 1;
+          EP.logz1 = sm.logz; EP.logz2 = nullptr; EP.pyy = c->d_ident; EP.pyy_tstride = 0;
+          EP.ny = q * q; EP.q = 1; EP.mirror = 0; EP.cap_out = cap;
+          EP.out = o2.cores; EP.obond = o2.bonds; EP.ostride = o2.stride; EP.ologz = o2.logz;
+          pl2.probs.push_back(EP); pl2.cost.push_back(1.0);
+          EnvProb VP{};
+          VP.in = o2.cores; VP.ibond = o2.bonds; VP.istride = o2.stride; VP.ilogz = o2.logz; VP.p = q * q;
+          VP.dst = c->slot_cores(eo); VP.dbond = c->slot_bonds(eo); VP.dstride = c->core_stride;
+          VP.marg = nullptr; VP.logz_out = nullptr; VP.bmax = cap;
+          off2.push_back(rvd2); rvd2 += (size_t)(L + 1) * cap;
+          ev2.push_back(VP);
+        }
+        if (cps2.empty()) continue;
+        rc = ensure_arena(c, c->scratch, sizeof(ComposeProb) * cps2.size() + 4096);
+        if (rc != MPBP_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->scratch.base, cps2.data(), sizeof(ComposeProb) * cps2.size(), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(compose_kernel, dim3(L, (unsigned)cps2.size()), dim3(256), 0, c->stream, (const ComposeProb*)c->scratch.base, L);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        rc = launch_engine(c, pl2, trunc, false, &ms_orth, &n_orth);
+        if (rc != MPBP_OK) return rc;
+        rc = run_env(ev2, off2, rvd2);
+        if (rc != MPBP_OK) return rc;
+      }
     }
   }
   // ---------------------------------------------------------------- f[i] (src/recursive_bp_factor.jl:163)

@@ -307,3 +307,39 @@ def test_two_rank_sharded_sweeps_equal_single_rank(tmp_path):
     import json
     j2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+
+
+def test_damping_loopy_matches_oracle():
+    """set_msg! with damp > 0 (reference src/recursive_bp_factor.jl:168-179): _compose + compress! + normalize!."""
+    N, T, Mb = 8, 6, 6
+    lam, rho, gam = 0.2, 0.1, 0.15
+    A, phi = _loopy(N, T, lam, rho, gam)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    for s in range(3):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0, damp=0.3)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True, damp=0.3)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+        import ctypes as C
+        f = np.zeros(N)
+        bp._L.mpbp_free_energy(bp._h, f.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.abs(f - obp.f).max() < RTOL * max(1.0, np.abs(obp.f).max()), f"sweep {s}"
+    pb, _ = M.pair_beliefs(bp)
+    opb, _ = O.pair_beliefs(obp)
+    assert _rel(_flat(pb), _flat(opb)) < RTOL
+
+
+def test_damping_infinite_graph_compounds_like_reference():
+    """Infinite regular graph with damping: the reference's loop re-reads bp.mu[1] for each of the k aliased
+    out-edges, so the damping compounds k times per iteration (test/glauber_infinite_graph.jl:22)."""
+    T, k = 5, 3
+    w = [M.HomogeneousGlauberFactor(0.3, 0.1, 1.0)] * (T + 1)
+    ow = [OF.HomogeneousGlauberFactor(0.3, 0.1, 1.0)] * (T + 1)
+    phi = [np.array([0.7, 0.3]) if t == 0 else np.ones(2) for t in range(T + 1)]
+    bp = M.mpbp_infinite_graph(k, w, 2, phi, max_bond=8)
+    obp = O.mpbp_infinite_graph(k, ow, 2, phi)
+    for s in range(6):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(8), tol=0.0, damp=0.4)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(8), tol=0.0, damp=0.4)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"iteration {s}"
+    assert abs(M.bethe_free_energy(bp) - O.bethe_free_energy(obp)) < RTOL * max(1.0, abs(O.bethe_free_energy(obp)))
