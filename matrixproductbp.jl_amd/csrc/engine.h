@@ -39,6 +39,7 @@ struct EngCfg {
   int32_t lds_gemm, lds_qr, lds_misc, lds_A1c, lds_A2c, lds_E, lds_JA, lds_JV, lds_rdim;
   mpbp_trunc trunc;
   wg::Prof* prof;     // optional phase timers (null = off)
+  int32_t force_generic;  // debug: take the large-problem code paths (global-memory QR panel)
 };
 
 struct EngStats {
@@ -171,7 +172,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
            [=](int j) { return (int64_t)(j % r1) + (int64_t)ldY * (j / r1); }, false);
     }
     PROF(PH_Y2);
-    qr_r(Y, ldY, rowsY, Bm, ldsQ, ldsG, pr, &plast, PH_QR1_PANEL, PH_QR1_TRAIL);
+    qr_r(Y, ldY, rowsY, Bm, ldsQ, ldsG, pr, &plast, PH_QR1_PANEL, PH_QR1_TRAIL, cfg.force_generic != 0);
     const int kmax = min(rowsY, Bm);
     // scale = max |R| over the upper trapezoid; Lf^T = R / scale  (column loops: no integer division)
     const int lane_ = tid & 63, wave_ = tid >> 6;
@@ -269,7 +270,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
          Nt, [=](int kk) { return (int64_t)Rr * kk; }, [=](int j) { return j; }, false,
          Mt, [=](int i) { return i; }, [=](int j) { return (int64_t)ldM * j; }, false, ldsG);
     PROF(PH_MT);
-    qr_r(Mt, ldM, r1, Rr, ldsQ, ldsG, pr, &plast, PH_QR2_PANEL, PH_QR2_TRAIL);
+    qr_r(Mt, ldM, r1, Rr, ldsQ, ldsG, pr, &plast, PH_QR2_PANEL, PH_QR2_TRAIL, cfg.force_generic != 0);
     const int k2 = min(r1, Rr);
     // Left singular vectors of M_t = right singular vectors of R2.  Hestenes on the columns of
     // JA = R2^T [Rr x k2] (the "L form": about half the sweeps of the R form) WITHOUT accumulating V:

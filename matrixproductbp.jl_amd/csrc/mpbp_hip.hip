@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -473,7 +474,12 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   const int64_t base = l;
   const int64_t coresE = ((nA1 + 3) & ~3) + ((nA2 + 3) & ~3) + ((nE + 3) & ~3);
   const int64_t jac = (((int64_t)(nmax + 1) * nmax + 3) & ~3);     // JA only (V is not accumulated)
-  bool cores_fit = base + coresE <= budget, jac_fit = base + jac <= budget;
+  // MPBP_DEBUG_FORCE_GENERIC=1 forces the large-problem paths (operands in global memory, global QR panel)
+  // on small inputs so that tests can cover them
+  const char* dbg = getenv("MPBP_DEBUG_FORCE_GENERIC");
+  const bool force = dbg && dbg[0] == '1';
+  cfg.force_generic = force ? 1 : 0;
+  bool cores_fit = !force && base + coresE <= budget, jac_fit = !force && base + jac <= budget;
   if (cores_fit) { int64_t o = base; cfg.lds_A1c = (int32_t)o; o += (nA1 + 3) & ~3; cfg.lds_A2c = (int32_t)o; o += (nA2 + 3) & ~3; cfg.lds_E = (int32_t)o; }
   else { cfg.lds_A1c = cfg.lds_A2c = cfg.lds_E = -1; }
   if (jac_fit) { cfg.lds_JA = (int32_t)base; cfg.lds_JV = -1; }

@@ -914,7 +914,7 @@ __device__ __forceinline__ void qr_tile_update_all(double* Y, long ld, int rows3
 
 // `big`: >= WG_WAVES*512 doubles of LDS scratch (may alias the gemm tile buffers)
 __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double* big, Prof* pr = nullptr,
-                     unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0) {
+                     unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   double* red = lds;                    // [WG_WAVES*16]
@@ -932,7 +932,7 @@ __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double
   (void)rows16;
   for (int j0 = 0; j0 < kmax;) {
     const int nb = min(QR_NB, kmax - j0);
-    const bool fast = rows - j0 <= QR_RS * WG_THREADS;
+    const bool fast = !force_generic && rows - j0 <= QR_RS * WG_THREADS;
     if (tid < 256) Ts[tid] = 0.0;
     if (tid < 16) tau[tid] = 0.0;
     __syncthreads();

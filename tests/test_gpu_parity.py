@@ -343,3 +343,20 @@ def test_damping_infinite_graph_compounds_like_reference():
         O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(8), tol=0.0, damp=0.4)
         assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"iteration {s}"
     assert abs(M.bethe_free_energy(bp) - O.bethe_free_energy(obp)) < RTOL * max(1.0, abs(O.bethe_free_energy(obp)))
+
+
+def test_large_problem_code_paths_forced(monkeypatch):
+    """Configs 3-5 (bond 30-64) use code paths that small tests never reach: operands and Jacobi buffers in
+    global memory instead of LDS, the global-memory QR panel (> 2048 rows).  MPBP_DEBUG_FORCE_GENERIC=1 forces
+    them on a small loopy case; results must still match the oracle."""
+    monkeypatch.setenv("MPBP_DEBUG_FORCE_GENERIC", "1")
+    N, T, Mb = 8, 6, 6
+    lam, rho, gam = 0.2, 0.1, 0.15
+    A, phi = _loopy(N, T, lam, rho, gam)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    for s in range(2):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+    assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
