@@ -161,6 +161,9 @@ int mpbp_sweep(mpbp_ctx* ctx, const int32_t* nodes, int32_t n_nodes, mpbp_trunc 
 
 /* beliefs(bp) (src/mpbp.jl:237): out[x + q*(t + (T+1)*i)] */
 int mpbp_beliefs(mpbp_ctx* ctx, double* out);
+/* `bp.b[node]` as a normalised MPEM1 train (cores [b_t, b_{t+1}, q], z = 1): what twovar_marginals /
+ * autocorrelations (src/mpbp.jl:245-255) read.  bonds: int32[T+2]; data == NULL only fills `bonds` (size query). */
+int mpbp_get_belief_train(mpbp_ctx* ctx, int32_t node, int32_t* bonds, double* data, int64_t data_capacity);
 /* pair_beliefs(bp) (src/mpbp.jl:202-235): out[x_src + q*(x_dst + q*(t + (T+1)*e))];
  * logz_pair[e] = log z_ij of the edge (the host folds (1/d_j - 1/2) weights, src/mpbp.jl:230) */
 int mpbp_pair_beliefs(mpbp_ctx* ctx, double* out, double* logz_pair);

@@ -47,7 +47,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["mpbp_create", "mpbp_destroy", "mpbp_last_error", "mpbp_slab_layout", "mpbp_slab_pointers",
            "mpbp_set_factor", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
-           "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_pair_beliefs",
+           "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_get_belief_train", "mpbp_pair_beliefs",
            "mpbp_free_energy", "mpbp_logz", "mpbp_set_profiling", "mpbp_phase_profile", "mpbp_selftest_gemm", "mpbp_selftest_qr", "mpbp_selftest_qr_bench",
            "mpbp_selftest_svd"]
 
@@ -101,6 +101,7 @@ def lib():
     L.mpbp_sweep.argtypes = [C.c_void_p, ip, C.c_int32, Trunc, C.c_double, C.POINTER(Stats)]
     L.mpbp_beliefs.argtypes = [C.c_void_p, dp]
     L.mpbp_pair_beliefs.argtypes = [C.c_void_p, dp, dp]
+    L.mpbp_get_belief_train.argtypes = [C.c_void_p, C.c_int32, ip, dp, C.c_int64]
     L.mpbp_free_energy.argtypes = [C.c_void_p, dp]
     L.mpbp_logz.argtypes = [C.c_void_p, dp, dp]
     L.mpbp_set_profiling.argtypes = [C.c_void_p, C.c_int32]

@@ -66,6 +66,8 @@ struct mpbp_ctx {
   hipStream_t stream = nullptr;
   // persistent outputs
   double* d_beliefs = nullptr;    // [q][L][N]
+  double* d_btrain = nullptr; int32_t* d_bbond = nullptr;   // normalised belief trains (MPEM1, bond <= q*cap), optional
+  int64_t bt_stride = 0, bt_slot = 0;
   double* d_logz_node = nullptr;  // [N]
   double* d_logz_pos = nullptr;   // [nnz]  log z_{i->j} per neighbour position
   std::vector<double> h_logz_node, h_logz_pos, h_f;
@@ -159,6 +161,21 @@ extern "C" int mpbp_create(mpbp_ctx** out, const mpbp_desc* d) {
     hipMemset(c->d_logz_node, 0, sizeof(double) * c->N);
     hipMemset(c->d_logz_pos, 0, sizeof(double) * nnz);
   }
+  {
+    // belief trains `bp.b[i]` are kept on the device when they fit comfortably (needed by twovar_marginals /
+    // autocorrelations, reference src/mpbp.jl:245-255); otherwise mpbp_get_belief_train reports EUNSUPPORTED
+    const int64_t capb = (int64_t)c->q * c->cap;
+    c->bt_stride = capb * capb * c->q;
+    c->bt_slot = c->bt_stride * c->L;
+    size_t freeb = 0, totb = 0;
+    hipMemGetInfo(&freeb, &totb);
+    const size_t need = sizeof(double) * (size_t)c->bt_slot * c->N;
+    if (need < freeb / 8) {
+      if (hipMalloc(&c->d_btrain, need) != hipSuccess) c->d_btrain = nullptr;
+      if (c->d_btrain && hipMalloc(&c->d_bbond, sizeof(int32_t) * (c->L + 1) * c->N) != hipSuccess) { hipFree(c->d_btrain); c->d_btrain = nullptr; }
+      if (c->d_bbond) hipMemset(c->d_bbond, 0, sizeof(int32_t) * (c->L + 1) * c->N);
+    }
+  }
   c->h_logz_node.assign(c->N, 0.0); c->h_logz_pos.assign(nnz, 0.0); c->h_f.assign(c->N, 0.0);
   c->phi.assign((size_t)c->q * c->L * c->N, 1.0);
   c->psi.assign((size_t)c->q * c->q * c->L * c->E, 1.0);
@@ -174,7 +191,7 @@ extern "C" void mpbp_destroy(mpbp_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->own_cores && c->d_cores) hipFree(c->d_cores);
   if (c->own_bonds && c->d_bonds) hipFree(c->d_bonds);
-  for (void* p : {(void*)c->d_beliefs, (void*)c->d_logz_node, (void*)c->d_logz_pos, (void*)c->d_stats, (void*)c->d_counter, (void*)c->d_prof,
+  for (void* p : {(void*)c->d_beliefs, (void*)c->d_logz_node, (void*)c->d_logz_pos, (void*)c->d_stats, (void*)c->d_counter, (void*)c->d_prof, (void*)c->d_btrain, (void*)c->d_bbond,
                   (void*)c->d_one, (void*)c->d_ones, (void*)c->d_ident, (void*)c->d_tab, (void*)c->arena.base, (void*)c->scratch.base})
     if (p) hipFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -770,7 +787,8 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
       const DevTrain& ct = tr[fr.ct];
       EnvProb P{};
       P.in = ct.cores; P.ibond = ct.bonds; P.istride = ct.stride; P.ilogz = ct.logz; P.p = q;
-      P.dst = nullptr; P.dbond = nullptr; P.dstride = 0;
+      P.dst = c->d_btrain ? c->d_btrain + (int64_t)i * c->bt_slot : nullptr;
+      P.dbond = c->d_btrain ? c->d_bbond + (int64_t)i * (L + 1) : nullptr; P.dstride = c->bt_stride;
       P.marg = c->d_beliefs + (size_t)q * L * i; P.logz_out = c->d_logz_node + i; P.bmax = capct;
       rv_off.push_back(rv_doubles); rv_doubles += (size_t)(L + 1) * capct;
       eps.push_back(P);
@@ -882,6 +900,30 @@ extern "C" int mpbp_logz(mpbp_ctx* c, double* ln, double* lm) {
     // per edge: value of the last neighbour position writing that edge
     for (int e = 0; e < c->E; e++) lm[e] = 0.0;
     for (int p = 0; p < c->nnz(); p++) lm[c->out_edge[p]] = c->h_logz_pos[p];
+  }
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_get_belief_train(mpbp_ctx* c, int32_t node, int32_t* bonds, double* data, int64_t data_capacity) {
+  if (!c || !bonds) return MPBP_EINVAL;
+  if (node < 0 || node >= c->N) return c->fail(MPBP_EINVAL, "node %d out of range", node);
+  if (!c->d_btrain) return c->fail(MPBP_EUNSUPPORTED, "belief trains are not kept on this context (not enough device memory)");
+  hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int L = c->L;
+  HIPCHK(c, hipMemcpy(bonds, c->d_bbond + (int64_t)node * (L + 1), sizeof(int32_t) * (L + 1), hipMemcpyDeviceToHost));
+  if (bonds[0] == 0) return c->fail(MPBP_EINVAL, "node %d has not been updated yet", node);
+  if (!data) return MPBP_OK;                      // size query
+  int64_t need = 0;
+  for (int t = 0; t < L; t++) need += (int64_t)bonds[t] * bonds[t + 1] * c->q;
+  if (need > data_capacity) return c->fail(MPBP_EINVAL, "buffer too small: need %lld doubles", (long long)need);
+  std::vector<double> slot((size_t)c->bt_slot);
+  HIPCHK(c, hipMemcpy(slot.data(), c->d_btrain + (int64_t)node * c->bt_slot, sizeof(double) * c->bt_slot, hipMemcpyDeviceToHost));
+  double* dst = data;
+  for (int t = 0; t < L; t++) {
+    const int64_t n = (int64_t)bonds[t] * bonds[t + 1] * c->q;
+    memcpy(dst, slot.data() + (int64_t)t * c->bt_stride, sizeof(double) * n);
+    dst += n;
   }
   return MPBP_OK;
 }

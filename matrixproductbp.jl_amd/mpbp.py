@@ -18,7 +18,7 @@ from .factors import RecursiveBPFactor
 
 __all__ = ["IndexedBiDiGraph", "InfiniteRegularGraph", "InfiniteBipartiteRegularGraph", "MPBP", "mpbp",
            "mpbp_infinite_graph", "mpbp_infinite_bipartite_graph", "iterate", "onebpiter", "CB_BP", "beliefs",
-           "means", "pair_beliefs", "bethe_free_energy", "reset_messages", "TruncThresh", "TruncBond",
+           "means", "belief_train", "twovar_marginals", "autocorrelations", "autocovariances", "pair_beliefs", "bethe_free_energy", "reset_messages", "TruncThresh", "TruncBond",
            "TruncBondMax", "TruncBondThresh", "default_truncator", "color_classes"]
 
 
@@ -395,6 +395,70 @@ def beliefs(bp: MPBP):
     _lib.check(bp._L.mpbp_beliefs(bp._h, _dp(buf)), bp._h)
     out = buf.reshape(out.shape, order="F")
     return [[out[:, t, i].copy() for t in range(bp.T + 1)] for i in range(bp.g.nv())]
+
+
+def belief_train(bp: MPBP, i: int):
+    """`bp.b[i]`: the belief as a normalised MPEM1 (list over t of arrays [b_t, b_{t+1}, q])."""
+    bonds = np.zeros(bp.T + 2, dtype=np.int32)
+    _lib.check(bp._L.mpbp_get_belief_train(bp._h, int(i), _ip(bonds), None, 0), bp._h)
+    sizes = bonds[:-1].astype(np.int64) * bonds[1:] * bp.q
+    data = np.zeros(int(sizes.sum()))
+    _lib.check(bp._L.mpbp_get_belief_train(bp._h, int(i), _ip(bonds), _dp(data), data.size), bp._h)
+    out, o = [], 0
+    for t in range(bp.T + 1):
+        out.append(data[o:o + int(sizes[t])].reshape((bonds[t], bonds[t + 1], bp.q), order="F").copy())
+        o += int(sizes[t])
+    return out
+
+
+def twovar_marginals(cores, maxdist=None):
+    """TensorTrains `twovar_marginals` for an MPEM1: `out[t][u][x_t, x_u]`, t < u <= t + maxdist, each
+    normalised (used by beliefs_tu / autocorrelations, reference src/mpbp.jl:239-255)."""
+    L = len(cores)
+    maxdist = L if maxdist is None else maxdist
+    summed = [c.sum(axis=2) for c in cores]
+    r = [None] * (L + 1)
+    r[L] = np.ones(1)
+    for t in range(L - 1, -1, -1):
+        v = summed[t] @ r[t + 1]
+        r[t] = v / np.abs(v).max()
+    out = [[None] * L for _ in range(L)]
+    lv = np.ones(1)
+    for t in range(L):
+        mid = np.einsum("m,mnx->xn", lv, cores[t])
+        for u in range(t + 1, min(L, t + maxdist + 1)):
+            p = np.einsum("xm,mny,n->xy", mid, cores[u], r[u + 1])
+            out[t][u] = p / p.sum()
+            mid = mid @ summed[u]
+            mid = mid / np.abs(mid).max()
+        lv = lv @ summed[t]
+        lv = lv / np.abs(lv).max()
+    return out
+
+
+def autocorrelations(f, bp: MPBP, sites=None, maxdist=None):
+    """src/mpbp.jl:245-255: `r[i][t, u] = <f(x_i^t) f(x_i^u)>` for t < u (0 elsewhere)."""
+    sites = range(bp.g.nv()) if sites is None else sites
+    out = []
+    for i in sites:
+        tv = twovar_marginals(belief_train(bp, i), maxdist)
+        L = bp.T + 1
+        r = np.zeros((L, L))
+        fx = np.array([f(x + 1, i) for x in range(bp.q)])
+        for t in range(L):
+            for u in range(t + 1, L):
+                if tv[t][u] is not None:
+                    r[t, u] = fx @ tv[t][u] @ fx
+        out.append(r)
+    return out
+
+
+def autocovariances(f, bp: MPBP, sites=None, maxdist=None):
+    """src/mpbp.jl:288-294: `r - mu mu'`."""
+    sites = list(range(bp.g.nv())) if sites is None else list(sites)
+    mu = means(f, bp)
+    r = autocorrelations(f, bp, sites, maxdist)
+    return [ri - np.outer(mu[i], mu[i]) for ri, i in zip(r, sites)]
 
 
 def means(f, bp: MPBP):

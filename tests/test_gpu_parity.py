@@ -360,3 +360,23 @@ def test_large_problem_code_paths_forced(monkeypatch):
         O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
         assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
     assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
+
+
+def test_autocorrelations_match_enumeration():
+    """reference test/sis_small_tree.jl:36-49: two-time observables from the belief trains (`bp.b[i]`)."""
+    from oracle.exact import exact_autocorrelations
+    A, lam, rho, alpha, phi, T = _sis_star_inputs()
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, 2, T, phi=phi, max_bond=16)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBondMax(4), schedule="colored")
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, [2] * 4, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    f = lambda x, i: x - 1
+    r = M.autocorrelations(f, bp)
+    rex = exact_autocorrelations(f, obp, p)
+    assert max(np.abs(a - b).max() for a, b in zip(r, rex)) < 1e-9
+    c = M.autocovariances(f, bp)
+    assert np.isfinite(np.array(c)).all()
+    # the belief train is normalised and reproduces the marginals
+    tr = M.belief_train(bp, 0)
+    assert tr[0].shape[0] == 1 and tr[-1].shape[1] == 1
