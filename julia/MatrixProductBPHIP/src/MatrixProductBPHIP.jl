@@ -5,7 +5,7 @@
 #
 # STATUS: written against include/mpbp_hip.h; the build image has no Julia, so this file has not been executed.
 # The Python mirror (matrixproductbp.jl_amd/mpbp.py) binds the same entry points and IS what the parity tests run.
-# UUIDs in Project.toml other than the package's own must be checked against the registry by the maintainer.
+# Dependency UUIDs in Project.toml are the ones the reference's own Project.toml lists.
 module MatrixProductBPHIP
 
 using MatrixProductBP, TensorTrains, IndexedGraphs, SparseArrays
