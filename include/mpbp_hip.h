@@ -183,6 +183,8 @@ int mpbp_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, const do
                        double* C);
 int mpbp_selftest_qr(int32_t device, int32_t rows, int32_t cols, const double* A, double* R);
 int mpbp_selftest_qr_bench(int32_t device, int32_t rows, int32_t cols, int32_t nblocks, int32_t reps, double* ms_out);
+int mpbp_selftest_jacobi_bench(int32_t device, int32_t m, int32_t n, int32_t nblocks, int32_t variant,
+                               int32_t reps, double* ms_out, double* avg_sweeps);
 int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, const double* A, double* sigma,
                       double* V);
 

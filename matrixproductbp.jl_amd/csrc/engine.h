@@ -14,40 +14,9 @@
 //       N_t = C_{t-1} A_t (structured), M_t = N_t Lf_{t+1}; left singular vectors of M_t by QR(M_t^T)
 //       + one-sided Jacobi; SVDTrunc rule on the singular values; new core = U, carry C_t = U^T N_t.
 // Cores keep the ORIGINAL bond basis on the right, so Q is never formed or stored.
-#pragma once
-#include "wg_blocks.h"
-#include "../../include/mpbp_hip.h"
-
-struct EngProb {
-  const double* A1; const int32_t* bond1; int64_t stride1; int32_t ny1;   // cores [m,n,y1,xi]
-  const double* A2; const int32_t* bond2; int64_t stride2; int32_t ny2;   // cores [m,n,y2,xi]
-  const double* logz1; const double* logz2;                               // may be null (= 0)
-  const double* pyy; int64_t pyy_tstride;   // pyy[tp*tstride + y + ny*(y1 + ny1*(y2 + ny2*xi))]
-  int32_t ny, q, mirror, cap_out;
-  double* out; int32_t* obond; int64_t ostride; double* ologz;            // output cores [m,n,y,xi]
-};
-
-struct EngCfg {
-  int32_t L;
-  int32_t Bmax;        // max product bond  (cap1*cap2)
-  int32_t nmax;        // max rows of M_t   (cap_out*ny*q)
-  // per-slot global scratch layout (offsets in doubles)
-  int64_t off_Lf, lf_stride;   // (L+1) triangular factors, lf_stride doubles each
-  int64_t off_Z, off_Y, off_C0, off_C1, off_T1, off_Nt, off_Mt, off_JA, off_JV, off_A1c, off_A2c, off_E;
-  int64_t slot_doubles;
-  // LDS layout (offsets in doubles from the dynamic LDS base); negative => use the global copy
-  int32_t lds_gemm, lds_qr, lds_misc, lds_A1c, lds_A2c, lds_E, lds_JA, lds_JV, lds_rdim;
-  mpbp_trunc trunc;
-  wg::Prof* prof;     // optional phase timers (null = off)
-  int32_t force_generic;  // debug: take the large-problem code paths (global-memory QR panel)
-};
-
-struct EngStats {
-  unsigned long long maxerr_bits;
-  unsigned long long n_compress;
-  int32_t nan_flag, capacity_flag, jacobi_fail;
-  unsigned long long jac_sweeps, jac_calls;
-};
+#if !defined(WG_THREADS)
+#error "engine.h is included from kernels.h, once per workgroup-size variant"
+#endif
 
 namespace eng {
 
@@ -286,7 +255,13 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     }
     fro2 = wg_sum(fro2, red);
     __syncthreads();
-    int sw = jacobi_rsv(JA, ldJ, Rr, k2, nullptr, 0, red, ord, 60);
+    int sw;
+    {
+      ldbl* redl = (ldbl*)red;
+      __attribute__((address_space(3))) int* ordl = (__attribute__((address_space(3))) int*)ord;
+      sw = (cfg.lds_JA >= 0) ? jacobi_rsv((ldbl*)JA, ldJ, Rr, k2, nullptr, 0, redl, ordl, 60)
+                             : jacobi_rsv((gdbl*)JA, ldJ, Rr, k2, nullptr, 0, redl, ordl, 60);
+    }
     if (tid == 0) {
       if (sw < 0) stats->jacobi_fail = 1;
       atomicAdd(&stats->jac_sweeps, (unsigned long long)(sw < 0 ? 60 : sw));

@@ -2,25 +2,73 @@
 // (Pxy application, MPEM3 -> explicit MPEM2 embedding, environment scans for normalize!/marginals,
 // pair beliefs).  gfx950 only.
 #pragma once
-#include "engine.h"
+#include "wg_common.h"
+#include "engine_types.h"
 
 // ------------------------------------------------------------------------------------------------
-// engine launcher: persistent workgroups pull problems (sorted by decreasing cost) from a counter
+// The building blocks and the engine are compiled twice: `v512` - one 512-thread workgroup per CU for the
+// MFMA-heavy cavity products - and `v64` - single-wave workgroups, several per CU, for the small problems
+// (message finalisation, products with a bond-1 operand, low bond dimensions), whose cost is latency:
+// a single wave has no workgroup barrier to wait at and many of them hide each other's latency.
+// Engine launcher: persistent workgroups pull problems (sorted by decreasing cost) from a counter.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WG_THREADS)
-eng_kernel(const EngProb* probs, int nprob, int* counter, EngCfg cfg, double* scratch, EngStats* stats) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ int s_p;
-  double* slot = scratch + (int64_t)blockIdx.x * cfg.slot_doubles;
-  for (;;) {
-    if (threadIdx.x == 0) s_p = atomicAdd(counter, 1);
-    __syncthreads();
-    const int p = s_p;
-    __syncthreads();
-    if (p >= nprob) break;
-    eng::run_problem(probs[p], cfg, slot, lds, stats);
+#define MPBP_ENGINE_KERNEL(LB)                                                                                    \
+  __global__ void LB eng_kernel(const EngProb* probs, int nprob, int* counter, EngCfg cfg, double* scratch,       \
+                                EngStats* stats) {                                                                \
+    extern __shared__ __attribute__((aligned(16))) double lds[];                                                  \
+    __shared__ int s_p;                                                                                           \
+    double* slot = scratch + (int64_t)blockIdx.x * cfg.slot_doubles;                                              \
+    for (;;) {                                                                                                    \
+      if (threadIdx.x == 0) s_p = atomicAdd(counter, 1);                                                          \
+      __syncthreads();                                                                                            \
+      const int p = s_p;                                                                                          \
+      __syncthreads();                                                                                            \
+      if (p >= nprob) break;                                                                                      \
+      eng::run_problem(probs[p], cfg, slot, lds, stats);                                                          \
+    }                                                                                                             \
+  }                                                                                                               \
+  /* self-test / microbenchmark: Hestenes Jacobi on a pseudo-random m x n matrix held in LDS */                   \
+  __global__ void LB jac_bench_kernel(int m, int n, int* sweeps) {                                                \
+    extern __shared__ __attribute__((aligned(16))) double lds[];                                                  \
+    const int lda = m | 1;                                                                                        \
+    double* A = lds + 64 + n;                                                                                     \
+    unsigned long long st = 88172645463325252ULL + 977ULL * blockIdx.x;                                           \
+    for (int idx = threadIdx.x; idx < m * n; idx += WG_THREADS) {                                                 \
+      unsigned long long z = st + 0x9E3779B97F4A7C15ULL * (unsigned long long)(idx + 1);                          \
+      z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;           \
+      const int r = idx % m, c = idx / m;                                                                         \
+      A[r + lda * c] = (r >= c) ? ((double)(z % 2000001ULL) / 1e6 - 1.0) / (1.0 + c) : 0.0;                       \
+    }                                                                                                             \
+    __syncthreads();                                                                                              \
+    int sw = wg::jacobi_rsv((ldbl*)A, lda, m, n, nullptr, 0, (ldbl*)lds,                                              \
+                            (__attribute__((address_space(3))) int*)(lds + 64), 60);                 \
+    if (threadIdx.x == 0) sweeps[blockIdx.x] = sw;                                                                \
   }
-}
+
+#define WG_THREADS 512
+#define WG_WAVES 8
+namespace v512 {
+#include "wg_blocks.h"
+#include "engine.h"
+MPBP_ENGINE_KERNEL(__launch_bounds__(512))
+}  // namespace v512
+#undef WG_THREADS
+#undef WG_WAVES
+
+#define WG_THREADS 64
+#define WG_WAVES 1
+namespace v64 {
+#include "wg_blocks.h"
+#include "engine.h"
+MPBP_ENGINE_KERNEL(__launch_bounds__(64, 2))
+}  // namespace v64
+#undef WG_THREADS
+#undef WG_WAVES
+
+// everything below (self-tests) uses the 512-thread variant
+#define WG_THREADS 512
+#define WG_WAVES 8
+namespace wg = v512::wg;
 
 // ------------------------------------------------------------------------------------------------
 // prep: B_k[t][m,n,y,xi] = sum_xk Pxy[t][y,xk,xi] mu_{k->i}[t][m,n,xk,xi]
@@ -409,13 +457,15 @@ __global__ void __launch_bounds__(WG_THREADS) st_gemm_kernel(int M, int N, int K
            B, [=](int k) { return k; }, [=](int j) { return (int64_t)K * j; }, true,
            C, [=](int i) { return i; }, [=](int j) { return (int64_t)M * j; }, false, lds);
 }
-__global__ void __launch_bounds__(WG_THREADS) st_qr_kernel(double* Y, int ld, int rows, int cols) {
+__global__ void __launch_bounds__(WG_THREADS) st_qr_kernel(double* Y, int ld, int rows, int cols, wg::Prof* pr) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  wg::qr_r(Y + (int64_t)blockIdx.x * ld * (((cols + 15) & ~15) + 16), ld, rows, cols, lds, lds + wg::QR_LDS_DOUBLES);
+  unsigned long long last = pr ? wall_clock64() : 0ULL;
+  wg::qr_r(Y + (int64_t)blockIdx.x * ld * (((cols + 15) & ~15) + 16), ld, rows, cols, lds, lds + wg::QR_LDS_DOUBLES,
+           pr, &last, -1, -1);
 }
 __global__ void __launch_bounds__(WG_THREADS) st_svd_kernel(double* A, int m, int n, double* V, double* sigma, int* sweeps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  int sw = wg::jacobi_rsv(A, m, m, n, V, n, lds, reinterpret_cast<int*>(lds + 32), 60);
+  int sw = wg::jacobi_rsv((gdbl*)A, m, m, n, V, n, (ldbl*)lds, (__attribute__((address_space(3))) int*)(lds + 32), 60);
   for (int c = threadIdx.x; c < n; c += WG_THREADS) {
     double s = 0.0;
     for (int r = 0; r < m; r++) s += A[r + (int64_t)m * c] * A[r + (int64_t)m * c];

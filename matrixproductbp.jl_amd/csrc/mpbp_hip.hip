@@ -452,7 +452,16 @@ static int ensure_arena(mpbp_ctx* c, Arena& a, size_t bytes) {
 struct EngLaunchPlan {
   std::vector<EngProb> probs; std::vector<double> cost;
   int cap1 = 1, cap2 = 1, ny1 = 1, ny2 = 1, ny = 1, q = 1, capout = 1;
+  bool small = false;       // run on the single-wave engine variant (v64)
 };
+
+// A problem goes to the single-wave engine when every QR panel of its first sweep fits the register panel of
+// one wave (rows of Y_t = B*ny*q <= QR_RS*64): these are the latency-bound problems (finalisation, products with
+// the bond-1 initial train, low bond dimensions).  MPBP_DEBUG_NO_SMALL=1 sends everything to the 512-thread one.
+static inline bool small_problem(int64_t B, int ny, int q) {
+  static const bool off = [] { const char* e = getenv("MPBP_DEBUG_NO_SMALL"); return e && e[0] == '1'; }();
+  return !off && B * ny * q <= v64::wg::QR_RS * 64;
+}
 
 static inline int r16h(int x) { return (x + 15) & ~15; }
 
@@ -483,14 +492,17 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   // LDS: [gemm][qr][misc][rdim] fixed, then union{cores+E, jacobi} if they fit in 150 KiB
   int64_t l = 0;
   auto ltake = [&](int64_t n) { int64_t o = l; l += (n + 3) & ~int64_t(3); return (int32_t)o; };
-  cfg.lds_gemm = ltake(wg::GM_LDS_DOUBLES);
-  cfg.lds_qr = ltake(wg::QR_LDS_DOUBLES);
+  // the gemm region doubles as the QR's `big` scratch (WG_WAVES*512 doubles)
+  cfg.lds_gemm = ltake(pl.small ? 512 : v512::wg::GM_LDS_DOUBLES);
+  cfg.lds_qr = ltake(pl.small ? v64::wg::QR_LDS_DOUBLES : v512::wg::QR_LDS_DOUBLES);
   cfg.lds_misc = ltake(32 + nmax + (nmax + 1) / 2 + 4);
   cfg.lds_rdim = ltake((L + 2 + 1) / 2 + 2);
-  const int64_t budget = (150 * 1024) / 8;
+  // 512-thread variant: one workgroup per CU, 150 KiB; single-wave variant: four per CU
+  const int64_t budget = pl.small ? (38 * 1024) / 8 : (150 * 1024) / 8;
   const int64_t base = l;
   const int64_t coresE = ((nA1 + 3) & ~3) + ((nA2 + 3) & ~3) + ((nE + 3) & ~3);
-  const int64_t jac = (((int64_t)(nmax + 1) * nmax + 3) & ~3);     // JA only (V is not accumulated)
+  // JA only (V is not accumulated): [Rr | 1] x min(r1, Rr) with Rr <= nmax, r1 <= Bmax
+  const int64_t jac = (((int64_t)(nmax + 1) * std::min<int64_t>(nmax, Bmax) + 3) & ~3);
   // MPBP_DEBUG_FORCE_GENERIC=1 forces the large-problem paths (operands in global memory, global QR panel)
   // on small inputs so that tests can cover them
   const char* dbg = getenv("MPBP_DEBUG_FORCE_GENERIC");
@@ -518,10 +530,15 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   for (int i = 0; i < nprob; i++) sorted[i] = pl.probs[idx[i]];
   EngCfg cfg; size_t lds_bytes;
   plan_cfg(pl, c->L, trunc, cfg, lds_bytes);
-  cfg.prof = (c->profiling && count_as_orth) ? c->d_prof : nullptr;
-  HIPCHK(c, hipFuncSetAttribute((const void*)eng_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // phase timers cover the 512-thread cavity launches; MPBP_PROF_SMALL=1 covers the single-wave launches instead
+  static const bool prof_small = [] { const char* e = getenv("MPBP_PROF_SMALL"); return e && e[0] == '1'; }();
+  cfg.prof = (c->profiling && (prof_small ? pl.small : count_as_orth)) ? c->d_prof : nullptr;
+  const void* kern = pl.small ? (const void*)v64::eng_kernel : (const void*)v512::eng_kernel;
+  const int nthreads = pl.small ? 64 : 512;
+  HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   int per_cu = 1;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, eng_kernel, WG_THREADS, lds_bytes);
+  if (pl.small) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v64::eng_kernel, nthreads, lds_bytes);
+  else hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v512::eng_kernel, nthreads, lds_bytes);
   if (per_cu < 1) per_cu = 1;
   int nslots = std::min(nprob, c->num_cu * per_cu);
   // scratch: bounded by a budget; fewer slots if needed
@@ -538,7 +555,9 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (count_as_orth && c->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
-  hipLaunchKernelGGL(eng_kernel, dim3(nslots), dim3(WG_THREADS), lds_bytes, c->stream, d_probs, nprob, c->d_counter, cfg, d_scr, c->d_stats);
+  if (pl.small) hipLaunchKernelGGL(v64::eng_kernel, dim3(nslots), dim3(64), lds_bytes, c->stream, d_probs, nprob, c->d_counter, cfg, d_scr, c->d_stats);
+  else hipLaunchKernelGGL(v512::eng_kernel, dim3(nslots), dim3(512), lds_bytes, c->stream, d_probs, nprob, c->d_counter, cfg, d_scr, c->d_stats);
+  (void)kern;
   HIPCHK(c, hipGetLastError());
   if (e0) {
     hipEventRecord(e1, c->stream); hipEventSynchronize(e1);
@@ -695,11 +714,12 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
   }
   // ---------------------------------------------------------------- cavity ops, level by level
   for (int lev = 1; lev <= maxlevel; lev++) {
-    EngLaunchPlan pl; pl.q = q; pl.capout = cap;
+    EngLaunchPlan plb, pls; plb.q = pls.q = q; plb.capout = pls.capout = cap; pls.small = true;
     for (const OpRec& o : ops) {
       if (o.level != lev) continue;
       const NodeFactor& f = c->fac[o.node];
       const DevTrain &a = tr[o.in1], &b = tr[o.in2], &out = tr[o.out];
+      EngLaunchPlan& pl = small_problem((int64_t)a.cap * b.cap, out.ny, q) ? pls : plb;
       EngProb P{};
       P.A1 = a.cores; P.bond1 = a.bonds; P.stride1 = a.stride; P.ny1 = a.ny;
       P.A2 = b.cores; P.bond2 = b.bonds; P.stride2 = b.stride; P.ny2 = b.ny;
@@ -714,7 +734,9 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
       pl.cap1 = std::max(pl.cap1, a.cap); pl.cap2 = std::max(pl.cap2, b.cap);
       pl.ny1 = std::max(pl.ny1, a.ny); pl.ny2 = std::max(pl.ny2, b.ny); pl.ny = std::max(pl.ny, out.ny);
     }
-    int rc = launch_engine(c, pl, trunc, true, &ms_orth, &n_orth);
+    int rc = launch_engine(c, plb, trunc, true, &ms_orth, &n_orth);
+    if (rc != MPBP_OK) return rc;
+    rc = launch_engine(c, pls, trunc, false, &ms_orth, &n_orth);
     if (rc != MPBP_OK) return rc;
   }
   // ---------------------------------------------------------------- finalise messages + beliefs
@@ -749,6 +771,7 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
     }
     // engine (mirror): mpem2 |> compress!(:left) |> normalize_eachmatrix!
     EngLaunchPlan pl; pl.q = 1; pl.capout = cap; pl.cap1 = capct; pl.cap2 = 1; pl.ny1 = q * q; pl.ny2 = 1; pl.ny = q * q;
+    pl.small = small_problem(capct, q * q, 1);
     for (const FinRec& fr : fins) {
       const DevTrain &ct = tr[fr.ct], &out = tr[fr.out];
       EngProb P{};
@@ -815,6 +838,7 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
       for (int round = 0; round <= maxocc; round++) {      // aliased out-edges compound in the reference's loop order
         std::vector<ComposeProb> cps2; EngLaunchPlan pl2; std::vector<EnvProb> ev2; std::vector<size_t> off2; size_t rvd2 = 0;
         pl2.q = 1; pl2.capout = cap; pl2.cap1 = 2 * cap; pl2.cap2 = 1; pl2.ny1 = q * q; pl2.ny2 = 1; pl2.ny = q * q;
+        pl2.small = small_problem(2 * cap, q * q, 1);
         for (const FinRec& fr : fins) {
           if (fr.occ != round) continue;
           const int eo = c->out_edge[fr.p];
@@ -991,7 +1015,7 @@ extern "C" int mpbp_selftest_qr(int32_t device, int32_t rows, int32_t cols, cons
   double* dY;
   STCHK(hipMalloc(&dY, sizeof(double) * Y.size()));
   STCHK(hipMemcpy(dY, Y.data(), sizeof(double) * Y.size(), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 512) * 8, 0, dY, ld, rows, cols);
+  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 512) * 8, 0, dY, ld, rows, cols, (wg::Prof*)nullptr);
   STCHK(hipGetLastError()); STCHK(hipDeviceSynchronize());
   STCHK(hipMemcpy(Y.data(), dY, sizeof(double) * Y.size(), hipMemcpyDeviceToHost));
   const int k = std::min(rows, cols);
@@ -1013,18 +1037,52 @@ extern "C" int mpbp_selftest_qr_bench(int32_t device, int32_t rows, int32_t cols
   STCHK(hipMemcpy(dY0, Y.data(), sizeof(double) * per, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float tot = 0.f;
+  wg::Prof* dprof = nullptr;                 // MPBP_QR_PROF=1: per-phase split of the factorisation on stderr
+  if (getenv("MPBP_QR_PROF")) { STCHK(hipMalloc(&dprof, sizeof(wg::Prof))); STCHK(hipMemset(dprof, 0, sizeof(wg::Prof))); }
   for (int r = 0; r < reps + 1; r++) {
+    if (dprof && r == 1) STCHK(hipMemset(dprof, 0, sizeof(wg::Prof)));
     for (int b = 0; b < nblocks; b++) STCHK(hipMemcpyAsync(dY + per * b, dY0, sizeof(double) * per, hipMemcpyDeviceToDevice, 0));
     STCHK(hipDeviceSynchronize());
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(st_qr_kernel, dim3(nblocks), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 512) * 8, 0, dY, ld, rows, cols);
+    hipLaunchKernelGGL(st_qr_kernel, dim3(nblocks), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 512) * 8, 0, dY, ld, rows, cols, dprof);
     hipEventRecord(e1, 0);
     STCHK(hipEventSynchronize(e1));
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     if (r > 0) tot += ms;
   }
   *ms_out = tot / reps;
+  if (dprof) {
+    wg::Prof hp; STCHK(hipMemcpy(&hp, dprof, sizeof(hp), hipMemcpyDeviceToHost));
+    const char* nm[5] = {"panel_regs", "gram", "T_from_gram", "tile_update", "trail"};
+    for (int k = 0; k < 5; k++) fprintf(stderr, "  qr phase %-12s %8.3f ms per workgroup per launch\n", nm[k], hp.t[14 + k] * 1e-5 / nblocks / reps);
+    hipFree(dprof);
+  }
   hipFree(dY); hipFree(dY0); hipEventDestroy(e0); hipEventDestroy(e1);
+  return MPBP_OK;
+}
+
+// times `reps` launches of nblocks concurrent LDS-resident Jacobi SVDs (m x n); variant 0 = 512 threads, 1 = one wave
+extern "C" int mpbp_selftest_jacobi_bench(int32_t device, int32_t m, int32_t n, int32_t nblocks, int32_t variant,
+                                          int32_t reps, double* ms_out, double* avg_sweeps) {
+  STCHK(hipSetDevice(device));
+  int* dS; STCHK(hipMalloc(&dS, sizeof(int) * nblocks));
+  const size_t lds = sizeof(double) * (64 + n + (size_t)(m | 1) * n + 8);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float tot = 0.f;
+  for (int r = 0; r < reps + 1; r++) {
+    hipEventRecord(e0, 0);
+    if (variant == 1) hipLaunchKernelGGL(v64::jac_bench_kernel, dim3(nblocks), dim3(64), lds, 0, m, n, dS);
+    else hipLaunchKernelGGL(v512::jac_bench_kernel, dim3(nblocks), dim3(512), lds, 0, m, n, dS);
+    hipEventRecord(e1, 0);
+    STCHK(hipGetLastError()); STCHK(hipEventSynchronize(e1));
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0) tot += ms;
+  }
+  std::vector<int> hs(nblocks);
+  STCHK(hipMemcpy(hs.data(), dS, sizeof(int) * nblocks, hipMemcpyDeviceToHost));
+  double acc = 0; for (int v : hs) acc += v;
+  *ms_out = tot / reps; *avg_sweeps = acc / nblocks;
+  hipFree(dS); hipEventDestroy(e0); hipEventDestroy(e1);
   return MPBP_OK;
 }
 

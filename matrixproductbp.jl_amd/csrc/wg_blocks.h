@@ -11,30 +11,13 @@
 // f64 MFMA fragment maps (cdna_hip_programming.md section 3, "f64 MFMA does NOT use these maps"):
 //   A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][j = l&15];
 //   C/D: reg r of lane l is C[row = (l>>4) + 4r][col = l&15].
-#pragma once
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdint.h>
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
-
-#define WG_THREADS 512
-#define WG_WAVES 8
+#if !defined(WG_THREADS) || !defined(WG_WAVES)
+#error "define WG_THREADS / WG_WAVES and include wg_common.h before wg_blocks.h (see kernels.h)"
+#endif
 
 namespace wg {
 
-// optional phase profile: lane 0 of the workgroup adds elapsed wall-clock ticks (100 MHz) per phase
-struct Prof { unsigned long long t[24]; };
-__device__ __forceinline__ void prof_mark(Prof* pr, unsigned long long& last, int phase) {
-  if (pr && threadIdx.x == 0) {
-    unsigned long long now = wall_clock64();
-    atomicAdd(&pr->t[phase], now - last);
-    last = now;
-  }
-}
-enum { PH_STAGE = 0, PH_Y1, PH_Y2, PH_QR1_PANEL, PH_QR1_TRAIL, PH_LF, PH_N, PH_MT, PH_QR2_PANEL, PH_QR2_TRAIL,
-       PH_JAC, PH_TRUNC, PH_CARRY, PH_NORM, PH_COUNT };
+using namespace wgc;
 
 constexpr int GM_MB = 96;    // rows per M block (6 MFMA row tiles)
 constexpr int GM_NT = 128;   // columns per N chunk (one 16-col tile per wave)
@@ -43,9 +26,10 @@ constexpr int GM_LDA = 112;  // LDS leading dims: == 16 (mod 32) doubles so that
 constexpr int GM_LDB = 144;  // ds_read_b64 half-wave land on disjoint banks
 constexpr int GM_LDS_DOUBLES = GM_KC * (GM_LDA + GM_LDB);   // 4096 doubles = 32 KiB
 
-__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
+template <class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
+__device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, const double* Sp, SRO sro, SCO sco,
+                                                     const double* Xp, XRO xro, XCO xco, double* Op, ORO oro, OCO oco,
+                                                     bool accumulate);
 
 // O(i,j) (+)= sum_k S(i,k) X(k,j),  i<M, j<N, k<K.
 //   S(i,k) = Sp[sro(i) + sco(k)],  X(k,j) = Xp[xro(k) + xco(j)],  O(i,j) = Op[oro(i) + oco(j)].
@@ -54,6 +38,11 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
 template <class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
 __device__ void gemm(int M, int N, int K, const double* Sp, SRO sro, SCO sco, const double* Xp, XRO xro,
                      XCO xco, bool xkfast, double* Op, ORO oro, OCO oco, bool accumulate, double* lds) {
+#if WG_THREADS != 512
+  // the LDS staging maps below are laid out for 512 threads; smaller workgroups take the barrier-free form
+  (void)xkfast; (void)lds;
+  gemm_direct(M, N, K, Sp, sro, sco, Xp, xro, xco, Op, oro, oco, accumulate);
+#else
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
@@ -163,6 +152,7 @@ __device__ void gemm(int M, int N, int K, const double* Sp, SRO sro, SCO sco, co
     }
   }
   __syncthreads();
+#endif
 }
 
 // Barrier-free variant for contractions whose M-side operand is small or cache resident (cores / coupling
@@ -259,7 +249,7 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // all threads receive the sum; red: >= WG_WAVES doubles; contains 2 barriers
-__device__ __forceinline__ double wg_sum(double v, double* red) {
+__device__ __forceinline__ double wg_sum(double v, ldbl* red) {
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -269,7 +259,7 @@ __device__ __forceinline__ double wg_sum(double v, double* red) {
   for (int w = 0; w < WG_WAVES; w++) s += red[w];
   return s;
 }
-__device__ __forceinline__ double wg_max(double v, double* red) {
+__device__ __forceinline__ double wg_max(double v, ldbl* red) {
   v = wave_max(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -280,8 +270,13 @@ __device__ __forceinline__ double wg_max(double v, double* red) {
   return s;
 }
 
+// `red` is always LDS scratch; callers that still hold it as a generic pointer go through these
+__device__ __forceinline__ double wg_sum(double v, double* red) { return wg_sum(v, (ldbl*)red); }
+__device__ __forceinline__ double wg_max(double v, double* red) { return wg_max(v, (ldbl*)red); }
+
 // max |x| over a strided 2D region (rows x cols, leading dim ld); all threads get it
-__device__ inline double wg_maxabs(const double* A, long ld, int rows, int cols, double* red) {
+template <class AP>
+__device__ inline double wg_maxabs(AP A, long ld, int rows, int cols, ldbl* red) {
   double m = 0.0;
   const long tot = (long)rows * cols;
   for (long idx = threadIdx.x; idx < tot; idx += WG_THREADS) {
@@ -291,6 +286,9 @@ __device__ inline double wg_maxabs(const double* A, long ld, int rows, int cols,
   }
   return wg_max(m, red);
 }
+
+template <class AP>
+__device__ inline double wg_maxabs(AP A, long ld, int rows, int cols, double* red) { return wg_maxabs(A, ld, rows, cols, (ldbl*)red); }
 
 // ---------------------------------------------------------------------------------------------
 // Blocked Householder QR, R only, in place.
@@ -373,11 +371,11 @@ __device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane, int&
 // One column step of the register panel with the column index JJ a compile-time constant: only the
 // columns c >= JJ are touched (half the work of a fixed 16-wide step, no register shifting).
 template <int JJ>
-__device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const bool (&rv)[QR_RS], double* Y, long ld,
-                                              int j0, double* red, double* tau, double* tot, double* rowb) {
+__device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const bool (&rv)[QR_RS], gdbl* Y, long ld,
+                                              int j0, ldbl* red, ldbl* tau, ldbl* tot, ldbl* rowb) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* totj = tot + 16 * (JJ & 1);
-  double* rowj = rowb + 16 * (JJ & 1);
+  ldbl* totj = tot + 16 * (JJ & 1);
+  ldbl* rowj = rowb + 16 * (JJ & 1);
   constexpr int NV = QR_NB - JJ;           // values to reduce: |x|^2 and NV-1 dots
   if (NV > 8) {
     double vals[16];
@@ -450,8 +448,8 @@ __device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const b
 }
 
 template <int JJ>
-__device__ __forceinline__ void qr_panel_steps(double (&P)[QR_RS][QR_NB], const bool (&rv)[QR_RS], double* Y, long ld,
-                                               int j0, int nb, double* red, double* tau, double* tot, double* rowb) {
+__device__ __forceinline__ void qr_panel_steps(double (&P)[QR_RS][QR_NB], const bool (&rv)[QR_RS], gdbl* Y, long ld,
+                                               int j0, int nb, ldbl* red, ldbl* tau, ldbl* tot, ldbl* rowb) {
   if constexpr (JJ < QR_NB) {
     if (JJ < nb) qr_panel_step<JJ>(P, rv, Y, ld, j0, red, tau, tot, rowb);
     qr_panel_steps<JJ + 1>(P, rv, Y, ld, j0, nb, red, tau, tot, rowb);
@@ -460,8 +458,8 @@ __device__ __forceinline__ void qr_panel_steps(double (&P)[QR_RS][QR_NB], const 
 
 // register-resident panel factorisation (rows - j0 <= QR_RS * WG_THREADS); T is built afterwards from the
 // Gram matrix of V (qr_gram + qr_T_from_gram).
-__device__ __attribute__((noinline)) void qr_panel_regs(double* Y, long ld, int rows, int j0, int nb, double* red,
-                                              double* tau, double* bc) {
+__device__ __attribute__((noinline)) void qr_panel_regs(gdbl* Y, long ld, int rows, int j0, int nb, ldbl* red,
+                                              ldbl* tau, ldbl* bc) {
   const int tid = threadIdx.x;
   double P[QR_RS][QR_NB];
   bool rv[QR_RS];
@@ -472,8 +470,8 @@ __device__ __attribute__((noinline)) void qr_panel_regs(double* Y, long ld, int 
 #pragma unroll
     for (int c = 0; c < QR_NB; c++) P[s][c] = (rv[s] && c < nb) ? Y[(long)(j0 + c) * ld + r] : 0.0;
   }
-  double* tot = bc;            // [2][16] wave-summed totals (double buffered by column parity)
-  double* rowb = bc + 32;      // [2][16] the pivot row of the panel
+  ldbl* tot = bc;            // [2][16] wave-summed totals (double buffered by column parity)
+  ldbl* rowb = bc + 32;      // [2][16] the pivot row of the panel
   qr_panel_steps<0>(P, rv, Y, ld, j0, nb, red, tau, tot, rowb);
   __syncthreads();
 }
@@ -484,14 +482,14 @@ __device__ __attribute__((noinline)) void qr_panel_regs(double* Y, long ld, int 
 // Vx / Vy / Vz are panels stored in place (unit lower-trapezoidal heads at column offsets jx / jy / jz with
 // nbx / nby / nbz reflectors).  Results in big[0..255] and big[256..511]; ends with a barrier.
 template <bool TWO>
-__device__ __forceinline__ void qr_gram(const double* Y, long ld, int rows32, int jrow, int jx, int nbx, int jy,
-                                        int nby, int jz, int nbz, double* big) {
+__device__ __forceinline__ void qr_gram(const gdbl* Y, long ld, int rows32, int jrow, int jx, int nbx, int jy,
+                                        int nby, int jz, int nbz, ldbl* big) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - jrow) >> 4;
-  const double* xcol = Y + (long)(jx + l15) * ld + jrow + 4 * g;
-  const double* ycol = Y + (long)(jy + l15) * ld + jrow + 4 * g;
-  const double* zcol = Y + (long)(jz + l15) * ld + jrow + 4 * g;
+  const gdbl* xcol = Y + (long)(jx + l15) * ld + jrow + 4 * g;
+  const gdbl* ycol = Y + (long)(jy + l15) * ld + jrow + 4 * g;
+  const gdbl* zcol = Y + (long)(jz + l15) * ld + jrow + 4 * g;
   d4 acc1 = d4{0, 0, 0, 0}, acc2 = d4{0, 0, 0, 0};
   auto head = [&](d4& v, int rb, int jv, int nbv) {
 #pragma unroll
@@ -505,9 +503,9 @@ __device__ __forceinline__ void qr_gram(const double* Y, long ld, int rows32, in
   d4 vx[2], vy[2], vz[2];
   auto load = [&](int rb, d4& a, d4& b, d4& c) {
     const int rbc = min(rb, nrb - 1);
-    a = *reinterpret_cast<const d4*>(xcol + 16 * rbc);
-    b = *reinterpret_cast<const d4*>(ycol + 16 * rbc);
-    if (TWO) c = *reinterpret_cast<const d4*>(zcol + 16 * rbc);
+    a = *reinterpret_cast<const gd4*>(xcol + 16 * rbc);
+    b = *reinterpret_cast<const gd4*>(ycol + 16 * rbc);
+    if (TWO) c = *reinterpret_cast<const gd4*>(zcol + 16 * rbc);
   };
   auto comp = [&](int rb, d4& a, d4& b, d4& c) {
     head(a, rb, jx, nbx); head(b, rb, jy, nby);
@@ -531,20 +529,33 @@ __device__ __forceinline__ void qr_gram(const double* Y, long ld, int rows32, in
     if (TWO) big[wave * 512 + 256 + (g + 4 * r) + 16 * l15] = acc2[r];
   }
   __syncthreads();
-  double s1 = 0.0;
-  if (tid < (TWO ? 512 : 256)) {
+  if (WG_WAVES > 1) {
+    constexpr int NVAL = TWO ? 512 : 256;
+    constexpr int PER = (NVAL + WG_THREADS - 1) / WG_THREADS;
+    double s1[PER];
 #pragma unroll
-    for (int w = 0; w < WG_WAVES; w++) s1 += big[w * 512 + tid];
+    for (int e = 0; e < PER; e++) {
+      const int idx = tid + e * WG_THREADS;
+      s1[e] = 0.0;
+      if (idx < NVAL) {
+#pragma unroll
+        for (int w = 0; w < WG_WAVES; w++) s1[e] += big[w * 512 + idx];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      const int idx = tid + e * WG_THREADS;
+      if (idx < NVAL) big[idx] = s1[e];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid < (TWO ? 512 : 256)) big[tid] = s1;
-  __syncthreads();
 }
 
 // T of the block reflector (dlarft) from the Gram matrix G = V^T V in `big`: row i of T depends only on its own
 // earlier entries, so lane i builds row i in registers with no synchronisation:
 //   T(i,j) = -tau_j sum_{i2=i}^{j-1} T(i,i2) G(i2,j)  (i < j),  T(j,j) = tau_j.
-__device__ __forceinline__ void qr_T_from_gram(const double* big, const double* tau, int nb, double* Ts) {
+__device__ __forceinline__ void qr_T_from_gram(const ldbl* big, const ldbl* tau, int nb, ldbl* Ts) {
   const int tid = threadIdx.x;
   if (tid < 16) {
     double trow[16];
@@ -570,12 +581,12 @@ __device__ __forceinline__ void qr_T_from_gram(const double* big, const double* 
 }
 
 // generic panel factorisation, panel in global memory (any number of rows)
-__device__ __attribute__((noinline)) void qr_panel_global(double* Y, long ld, int rows, int j0, int nb, double* red, double* Ts,
-                                       double* tau, double* bc) {
+__device__ __attribute__((noinline)) void qr_panel_global(gdbl* Y, long ld, int rows, int j0, int nb, ldbl* red, ldbl* Ts,
+                                       ldbl* tau, ldbl* bc) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int jj = 0; jj < nb; jj++) {
     const int col = j0 + jj;
-    double* x = Y + (long)col * ld;
+    gdbl* x = Y + (long)col * ld;
     double ss = 0.0;
     for (int r = col + 1 + tid; r < rows; r += WG_THREADS) { double v = x[r]; ss += v * v; }
     ss = wg_sum(ss, red);
@@ -635,12 +646,12 @@ __device__ __attribute__((noinline)) void qr_panel_global(double* Y, long ld, in
 // and a vmcnt(0)).  Requires: ld % 32 == 0, rows padded with zeros up to rows32, and the buffer to have
 // zero padding columns wherever a tile sticks out of `cols` (they stay zero: W = T^T V^T 0 = 0).
 template <int NT>
-__device__ __forceinline__ void qr_trail(double* Y, long ld, int rows32, int j0, int nb, int cb0, const double* Ts) {
+__device__ __forceinline__ void qr_trail(gdbl* Y, long ld, int rows32, int j0, int nb, int cb0, const ldbl* Ts) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - j0) >> 4;
-  const double* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
-  const double* ccol[NT];
+  const gdbl* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  const gdbl* ccol[NT];
   d4 w0[NT];
 #pragma unroll
   for (int q = 0; q < NT; q++) { ccol[q] = Y + (long)(cb0 + 16 * q + l15) * ld + j0 + 4 * g; w0[q] = d4{0, 0, 0, 0}; }
@@ -650,9 +661,9 @@ __device__ __forceinline__ void qr_trail(double* Y, long ld, int rows32, int j0,
     d4 sv[3], sc[3][NT];
     auto loadA = [&](int rb, d4& v, d4 (&c)[NT]) {
       const int rbc = min(rb, nrb - 1);
-      v = *reinterpret_cast<const d4*>(vcol + 16 * rbc);
+      v = *reinterpret_cast<const gd4*>(vcol + 16 * rbc);
 #pragma unroll
-      for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const d4*>(ccol[q] + 16 * rbc);
+      for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const gd4*>(ccol[q] + 16 * rbc);
       const bool keep = vkeep && rb < nrb;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -695,7 +706,7 @@ __device__ __forceinline__ void qr_trail(double* Y, long ld, int rows32, int j0,
 #pragma unroll
       for (int s2 = 0; s2 < 4; s2++) {
         const int k = 4 * s2 + g;               // reflector index
-        d2 x = *reinterpret_cast<const d2*>(Y + (long)(j0 + k) * ld + row);
+        d2 x = *reinterpret_cast<const gd2*>(Y + (long)(j0 + k) * ld + row);
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const int rho = row + e - j0;         // row relative to the panel's diagonal block
@@ -710,7 +721,7 @@ __device__ __forceinline__ void qr_trail(double* Y, long ld, int rows32, int j0,
       for (int q = 0; q < NT; q++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          c[q][r] = *reinterpret_cast<const d2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
+          c[q][r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
 #pragma unroll
       for (int q = 0; q < NT; q++) {
 #pragma unroll
@@ -723,7 +734,7 @@ __device__ __forceinline__ void qr_trail(double* Y, long ld, int rows32, int j0,
         }
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          *reinterpret_cast<d2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[q][r];
+          *reinterpret_cast<gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[q][r];
       }
     }
   }
@@ -734,14 +745,14 @@ __device__ __forceinline__ void qr_trail(double* Y, long ld, int rows32, int j0,
 //   (I - Vb Tb^T Vb^T)(I - Va Ta^T Va^T) C = C - Va Wa - Vb Wb,
 //   Wa = Ta^T Va^T C,   Wb = Tb^T (Vb^T C - S Wa),   S = Vb^T Va  (16x16, in LDS).
 template <int NT>
-__device__ __forceinline__ void qr_trail2(double* Y, long ld, int rows32, int j0, int nbb, int cb0,
-                                          const double* TsA, const double* TsB, const double* Sm) {
+__device__ __forceinline__ void qr_trail2(gdbl* Y, long ld, int rows32, int j0, int nbb, int cb0,
+                                          const ldbl* TsA, const ldbl* TsB, const ldbl* Sm) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - j0) >> 4;
-  const double* vacol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
-  const double* vbcol = Y + (long)(j0 + 16 + l15) * ld + j0 + 4 * g;
-  const double* ccol[NT];
+  const gdbl* vacol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  const gdbl* vbcol = Y + (long)(j0 + 16 + l15) * ld + j0 + 4 * g;
+  const gdbl* ccol[NT];
   d4 wa0[NT], wb0[NT];
 #pragma unroll
   for (int q = 0; q < NT; q++) {
@@ -753,10 +764,10 @@ __device__ __forceinline__ void qr_trail2(double* Y, long ld, int rows32, int j0
     d4 sa[3], sb[3], sc[3][NT];
     auto loadA = [&](int rb, d4& va, d4& vb, d4 (&c)[NT]) {
       const int rbc = min(rb, nrb - 1);
-      va = *reinterpret_cast<const d4*>(vacol + 16 * rbc);
-      vb = *reinterpret_cast<const d4*>(vbcol + 16 * rbc);
+      va = *reinterpret_cast<const gd4*>(vacol + 16 * rbc);
+      vb = *reinterpret_cast<const gd4*>(vbcol + 16 * rbc);
 #pragma unroll
-      for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const d4*>(ccol[q] + 16 * rbc);
+      for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const gd4*>(ccol[q] + 16 * rbc);
       const bool in = rb < nrb;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -806,8 +817,8 @@ __device__ __forceinline__ void qr_trail2(double* Y, long ld, int rows32, int j0
 #pragma unroll
       for (int s2 = 0; s2 < 4; s2++) {
         const int k = 4 * s2 + g;
-        d2 xa = *reinterpret_cast<const d2*>(Y + (long)(j0 + k) * ld + row);
-        d2 xb = *reinterpret_cast<const d2*>(Y + (long)(j0 + 16 + k) * ld + row);
+        d2 xa = *reinterpret_cast<const gd2*>(Y + (long)(j0 + k) * ld + row);
+        d2 xb = *reinterpret_cast<const gd2*>(Y + (long)(j0 + 16 + k) * ld + row);
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const int ra = row + e - j0, rbb = row + e - j0 - 16;
@@ -824,7 +835,7 @@ __device__ __forceinline__ void qr_trail2(double* Y, long ld, int rows32, int j0
       for (int q = 0; q < NT; q++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          c[q][r] = *reinterpret_cast<const d2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
+          c[q][r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
 #pragma unroll
       for (int q = 0; q < NT; q++) {
 #pragma unroll
@@ -837,7 +848,7 @@ __device__ __forceinline__ void qr_trail2(double* Y, long ld, int rows32, int j0
         }
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          *reinterpret_cast<d2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[q][r];
+          *reinterpret_cast<gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[q][r];
       }
     }
   }
@@ -845,17 +856,17 @@ __device__ __forceinline__ void qr_trail2(double* Y, long ld, int rows32, int j0
 
 // Update ONE 16-column tile (first column cb0) by panel (j0, nb) with all waves working on different rows:
 // W0 partials -> LDS, every wave then applies W = T^T W0 to its own 32-row stages.
-__device__ __forceinline__ void qr_tile_update_all(double* Y, long ld, int rows32, int j0, int nb, int cb0,
-                                                   const double* Ts, double* big) {
+__device__ __forceinline__ void qr_tile_update_all(gdbl* Y, long ld, int rows32, int j0, int nb, int cb0,
+                                                   const ldbl* Ts, ldbl* big) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - j0) >> 4;
-  const double* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
-  const double* ccol = Y + (long)(cb0 + l15) * ld + j0 + 4 * g;
+  const gdbl* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  const gdbl* ccol = Y + (long)(cb0 + l15) * ld + j0 + 4 * g;
   d4 acc = d4{0, 0, 0, 0};
   for (int rb = wave; rb < nrb; rb += WG_WAVES) {
-    d4 v = *reinterpret_cast<const d4*>(vcol + 16 * rb);
-    d4 c = *reinterpret_cast<const d4*>(ccol + 16 * rb);
+    d4 v = *reinterpret_cast<const gd4*>(vcol + 16 * rb);
+    d4 c = *reinterpret_cast<const gd4*>(ccol + 16 * rb);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int rho = 4 * g + e;
@@ -886,7 +897,7 @@ __device__ __forceinline__ void qr_tile_update_all(double* Y, long ld, int rows3
 #pragma unroll
     for (int s2 = 0; s2 < 4; s2++) {
       const int k = 4 * s2 + g;
-      d2 x = *reinterpret_cast<const d2*>(Y + (long)(j0 + k) * ld + row);
+      d2 x = *reinterpret_cast<const gd2*>(Y + (long)(j0 + k) * ld + row);
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         const int rho = row + e - j0;
@@ -897,7 +908,7 @@ __device__ __forceinline__ void qr_tile_update_all(double* Y, long ld, int rows3
       v[s2] = x;
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const d2*>(Y + (long)(cb0 + g + 4 * r) * ld + row);
+    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row);
 #pragma unroll
     for (int e = 0; e < 2; e++) {
       d4 a = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
@@ -907,55 +918,64 @@ __device__ __forceinline__ void qr_tile_update_all(double* Y, long ld, int rows3
       for (int r = 0; r < 4; r++) c[r][e] = a[r];
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) *reinterpret_cast<d2*>(Y + (long)(cb0 + g + 4 * r) * ld + row) = c[r];
+    for (int r = 0; r < 4; r++) *reinterpret_cast<gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row) = c[r];
   }
   __syncthreads();
 }
 
 // `big`: >= WG_WAVES*512 doubles of LDS scratch (may alias the gemm tile buffers)
-__device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double* big, Prof* pr = nullptr,
+__device__ void qr_r(double* Y_, long ld, int rows, int cols, double* lds_, double* big_, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
+  gdbl* Y = (gdbl*)Y_;                  // the matrix lives in HBM, the scratch in LDS: say so (see wg_common.h)
+  ldbl* lds = (ldbl*)lds_;
+  ldbl* big = (ldbl*)big_;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  double* red = lds;                    // [WG_WAVES*16]
-  double* Ts = lds + WG_WAVES * 16;     // [16*16] T, column-major Ts[i + 16*j]
-  double* tau = Ts + 256;               // [16]
-  double* bc = tau + 16;                // broadcast scratch [64 + 32]
+  ldbl* red = lds;                      // [WG_WAVES*16]
+  ldbl* Ts = lds + WG_WAVES * 16;       // [16*16] T, column-major Ts[i + 16*j]
+  ldbl* tau = Ts + 256;                 // [16]
+  ldbl* bc = tau + 16;                  // broadcast scratch [64 + 32]
   const int kmax = min(rows, cols);
+  const bool fine = pr && ph_panel < 0;       // self-test: finer phase split in slots 14..18
   const int rows16 = (rows + 15) & ~15;
   const int rows32 = (rows + 31) & ~31;      // ld >= rows32, rows [rows, rows32) zero
 
-  double* TsB = lds + QR_LDS_BASE;        // second T and the cross Gram S of a panel pair
-  double* Sm = TsB + 256;
-  double* tauB = Sm + 256;
+  ldbl* TsB = lds + QR_LDS_BASE;        // second T and the cross Gram S of a panel pair
+  ldbl* Sm = TsB + 256;
+  ldbl* tauB = Sm + 256;
   const int ncol16 = (cols + 15) >> 4;
   (void)rows16;
   for (int j0 = 0; j0 < kmax;) {
     const int nb = min(QR_NB, kmax - j0);
     const bool fast = !force_generic && rows - j0 <= QR_RS * WG_THREADS;
-    if (tid < 256) Ts[tid] = 0.0;
+    for (int i = tid; i < 256; i += WG_THREADS) Ts[i] = 0.0;
     if (tid < 16) tau[tid] = 0.0;
     __syncthreads();
     if (fast) {
       qr_panel_regs(Y, ld, rows, j0, nb, red, tau, bc);
+      if (fine) prof_mark(pr, *plast, 14);
       qr_gram<false>(Y, ld, rows32, j0, j0, nb, j0, nb, j0, nb, big);
+      if (fine) prof_mark(pr, *plast, 15);
       qr_T_from_gram(big, tau, nb, Ts);
+      if (fine) prof_mark(pr, *plast, 16);
     } else qr_panel_global(Y, ld, rows, j0, nb, red, Ts, tau, bc);
     // pair with the next panel when both are full-width register panels and a trailing matrix remains
     const int j1 = j0 + 16;
     const int nbb = min(QR_NB, kmax - j1);
     const bool pair = fast && nb == 16 && j1 < kmax && nbb == 16 && (j1 + 16 < cols);
-    if (pr) prof_mark(pr, *plast, ph_panel);
+    if (pr && !fine) prof_mark(pr, *plast, ph_panel);
     if (pair) {
       qr_tile_update_all(Y, ld, rows32, j0, 16, j1, Ts, big);
-      if (pr) prof_mark(pr, *plast, ph_trail);
+      if (pr) prof_mark(pr, *plast, fine ? 17 : ph_trail);
       if (tid < 16) tauB[tid] = 0.0;
       __syncthreads();
       qr_panel_regs(Y, ld, rows, j1, nbb, red, tauB, bc);
+      if (fine) prof_mark(pr, *plast, 14);
       qr_gram<true>(Y, ld, rows32, j0, j1, nbb, j1, nbb, j0, 16, big);   // Vb^T Vb and S = Vb^T Va in one pass
-      if (tid < 256) Sm[tid] = big[256 + tid];
+      for (int i = tid; i < 256; i += WG_THREADS) Sm[i] = big[256 + i];
+      if (fine) prof_mark(pr, *plast, 15);
       qr_T_from_gram(big, tauB, nbb, TsB);
-      if (pr) prof_mark(pr, *plast, ph_panel);
+      if (pr) prof_mark(pr, *plast, fine ? 16 : ph_panel);
     }
     // ------------------------------------------------------------------ trailing update
     const int cstart = pair ? j1 + 16 : j0 + nb;
@@ -977,7 +997,7 @@ __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double
       }
     }
     __syncthreads();
-    if (pr) prof_mark(pr, *plast, ph_trail);
+    if (pr) prof_mark(pr, *plast, fine ? 18 : ph_trail);
     j0 += pair ? 32 : 16;
   }
   (void)ncol16;
@@ -986,15 +1006,16 @@ __device__ void qr_r(double* Y, long ld, int rows, int cols, double* lds, double
 // ---------------------------------------------------------------------------------------------
 // One-sided Jacobi (Hestenes): A (m x n, ld lda) -> A V = U Sigma; V (n x n, ld ldv) accumulated from I
 // (V == nullptr: not accumulated - the rotated columns sigma_j u_j then carry the LEFT singular vectors).
-// Column norms of the final A are the singular values (unsorted).  8 lanes per column pair.
+// Column norms of the final A are the singular values (unsorted).  Up to 8 lanes per column pair (fewer when a round has more pairs than the workgroup has 8-lane groups).
 // Deflation: a column whose norm falls below 1e-14 ||A||_F is numerically null; it only carries rounding
 // noise, rotating it never converges and never matters, and it can never grow back - after every sweep the
 // null columns leave the tournament, so later sweeps run over the active columns only.
 // `red`: >= 16 doubles; `act`: >= n ints of LDS.  Returns the number of sweeps, or -1 if not converged.
 // lda / ldv should be odd (LDS bank spreading between the column pairs of different lane groups).
 // ---------------------------------------------------------------------------------------------
-__device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, double* red, int* act,
-                          int maxsweeps) {
+template <class AP>     // AP = ldbl* (matrix in LDS) or gdbl* (in HBM): typed so that the inner loops are ds_* / global_*
+__device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n, double* V, int ldv, ldbl* red,
+                                                    __attribute__((address_space(3))) int* act, int maxsweeps) {
   const int tid = threadIdx.x;
   if (V) {
     for (int idx = tid; idx < n * n; idx += WG_THREADS) {
@@ -1009,49 +1030,96 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
   for (int idx = tid; idx < m * n; idx += WG_THREADS) { double v = A[(idx % m) + (long)lda * (idx / m)]; fro2 += v * v; }
   fro2 = wg_sum(fro2, red);
   const double nul = 1e-28 * fro2;
-  const int sub = tid & 7;              // lane inside the 8-lane pair group
-  const int grp = tid >> 3;             // 64 groups per pass
   const double tol = 1e-15;
+  constexpr int JC = 12;                // rows per lane held in registers at a time
   int nact = n;
   int sweep = 0;
   bool conv = false;
   for (; sweep < maxsweeps; sweep++) {
     const int ne = (nact + 1) & ~1;       // even number of "players"
     const int npairs = ne / 2;
+    // lanes per column pair (at most 8): enough that a lane's share of a column fits the JC registers (the
+    // rotation then reuses the loaded values), and more if the workgroup still has a lane group for every pair
+    int lg = 3;
+    while (lg > 0 && (npairs << lg) > WG_THREADS) lg--;
+    while (lg < 3 && ((m + (1 << lg) - 1) >> lg) > JC) lg++;
+    const int LP = 1 << lg;
+    const int sub = tid & (LP - 1);       // lane inside the pair group
+    const int grp = tid >> lg;
+    const int rpl = (m + LP - 1) >> lg;   // rows per lane
     int rotated = 0;
     for (int round = 0; round < ne - 1; round++) {
-      for (int pb = 0; pb < npairs; pb += WG_THREADS / 8) {
+      for (int pb = 0; pb < npairs; pb += WG_THREADS >> lg) {
         const int pi = pb + grp;
         if (pi < npairs) {
           // round-robin tournament: player ne-1 fixed, others rotate
-          int p, q;
-          if (pi == 0) { p = ne - 1; q = round % (ne - 1); }
+          int p, q;                       // round < ne-1 and pi < ne/2: one conditional subtraction replaces %
+          if (pi == 0) { p = ne - 1; q = round; }
           else {
-            p = (round + pi) % (ne - 1);
-            q = (round + (ne - 1) - pi) % (ne - 1);
+            p = round + pi; p -= (p >= ne - 1) ? (ne - 1) : 0;
+            q = round + (ne - 1) - pi; q -= (q >= ne - 1) ? (ne - 1) : 0;
           }
           if (p > q) { int t_ = p; p = q; q = t_; }
           if (q < nact) {
             const int cp = act[p], cq = act[q];
-            double* ap = A + (long)lda * cp;
-            double* aq = A + (long)lda * cq;
+            AP ap = A + (long)lda * cp;
+            AP aq = A + (long)lda * cq;
+            // rows r = sub + LP*i of the two columns, JC per lane at a time with all loads in flight together
+            // (a single wave has no second wave to hide the LDS latency); when the whole column fits the JC
+            // registers the rotation reuses them instead of reading the columns again
             double al = 0, be = 0, ga = 0;
-            for (int r = sub; r < m; r += 8) { double x = ap[r], y = aq[r]; al += x * x; be += y * y; ga += x * y; }
+            double x[JC], y[JC];
+            auto loadc = [&](int i0) {
 #pragma unroll
-            for (int o = 4; o > 0; o >>= 1) {
+              for (int i = 0; i < JC; i++) {
+                const int r = sub + ((i0 + i) << lg);
+                const bool ok = r < m;
+                const int rc = ok ? r : sub;
+                const double xv = ap[rc], yv = aq[rc];
+                x[i] = ok ? xv : 0.0; y[i] = ok ? yv : 0.0;
+              }
+            };
+            for (int i0 = 0; i0 < rpl; i0 += JC) {
+              loadc(i0);
+#pragma unroll
+              for (int i = 0; i < JC; i++) { al += x[i] * x[i]; be += y[i] * y[i]; ga += x[i] * y[i]; }
+            }
+            for (int o = LP >> 1; o > 0; o >>= 1) {
               al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64);
             }
-            const double lim = tol * sqrt(al * be);
-            if (fabs(ga) > lim && al > nul && be > nul) {
+            if (ga * ga > (tol * tol) * (al * be) && al > nul && be > nul) {
               rotated = 1;
-              const double zeta = (be - al) / (2.0 * ga);
-              const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-              const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-              for (int r = sub; r < m; r += 8) { double x = ap[r], y = aq[r]; ap[r] = c * x - s * y; aq[r] = s * x + c * y; }
+              // t = tan(theta) = sgn(d) 2 ga / (|d| + sqrt(d^2 + 4 ga^2)), d = be - al  (smaller root);
+              // c = 1/sqrt(1 + t^2), s = c t: one sqrt, one reciprocal, one rsqrt - hardware seeds refined by
+              // Newton steps (the plain IEEE division / sqrt sequences dominate the cost of a rotation otherwise)
+              const double d = be - al, g2 = 2.0 * ga;
+              const double h2 = d * d + g2 * g2;
+              double rs = __builtin_amdgcn_rsq(h2);
+              rs = rs * (1.5 - 0.5 * h2 * rs * rs);
+              double hy = h2 * rs;                                   // sqrt(h2)
+              hy = hy + 0.5 * rs * (h2 - hy * hy);
+              const double den = fabs(d) + hy;
+              double rd = __builtin_amdgcn_rcp(den);
+              rd = rd * (2.0 - den * rd);
+              rd = rd * (2.0 - den * rd);
+              const double t = copysign(g2, d * ga) * rd;
+              const double o2 = 1.0 + t * t;
+              double c = __builtin_amdgcn_rsq(o2);
+              c = c * (1.5 - 0.5 * o2 * c * c);
+              c = c * (1.5 - 0.5 * o2 * c * c);
+              const double s = c * t;
+              for (int i0 = 0; i0 < rpl; i0 += JC) {
+                if (rpl > JC) loadc(i0);
+#pragma unroll
+                for (int i = 0; i < JC; i++) {
+                  const int r = sub + ((i0 + i) << lg);
+                  if (r < m) { ap[r] = c * x[i] - s * y[i]; aq[r] = s * x[i] + c * y[i]; }
+                }
+              }
               if (V) {
                 double* vp = V + (long)ldv * cp;
                 double* vq = V + (long)ldv * cq;
-                for (int r = sub; r < n; r += 8) { double x = vp[r], y = vq[r]; vp[r] = c * x - s * y; vq[r] = s * x + c * y; }
+                for (int r = sub; r < n; r += LP) { double x = vp[r], y = vq[r]; vp[r] = c * x - s * y; vq[r] = s * x + c * y; }
               }
             }
           }
@@ -1063,16 +1131,13 @@ __device__ int jacobi_rsv(double* A, int lda, int m, int n, double* V, int ldv, 
     double any = wg_max((double)rotated, red);
     if (any == 0.0) { conv = true; break; }
     // deflate: one thread per active column measures it, thread 0 compacts the list
-    int keep = 0, mycol = -1;
-    if (tid < nact) {
-      mycol = act[tid];
-      const double* ac = A + (long)lda * mycol;
+    for (int i = tid; i < nact; i += WG_THREADS) {     // every thread only touches its own entries
+      const int mycol = act[i];
+      AP ac = A + (long)lda * mycol;
       double s2 = 0.0;
       for (int r = 0; r < m; r++) s2 += ac[r] * ac[r];
-      keep = s2 > nul;
+      act[i] = (s2 > nul) ? mycol : -1;
     }
-    __syncthreads();
-    if (tid < nact) act[tid] = keep ? mycol : -1;
     __syncthreads();
     if (tid == 0) {
       int w = 0;

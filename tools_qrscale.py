@@ -1,3 +1,4 @@
+"""QR building block at different numbers of concurrent workgroups (contention vs latency floor)."""
 import ctypes as C, sys
 sys.path.insert(0, "/root/repo")
 import mpbp_amd
@@ -5,4 +6,4 @@ L = mpbp_amd._lib.lib()
 ms = C.c_double()
 for nb in (16, 64, 128, 256):
     L.mpbp_selftest_qr_bench(0, 1600, 400, nb, 2, C.byref(ms))
-    print(f"QR 1600x400, {nb} concurrent blocks: {ms.value:.2f} ms per launch")
+    print(f"QR 1600x400 x{nb} blocks: {ms.value:.2f} ms/launch", flush=True)
