@@ -25,13 +25,17 @@ using namespace wg;
 __device__ __forceinline__ int r16(int x) { return (x + 15) & ~15; }
 __device__ __forceinline__ int r32(int x) { return (x + 31) & ~31; }
 
+typedef __attribute__((address_space(1))) int32_t gint;
+typedef __attribute__((address_space(3))) int lint;
+
 // stage logical core t of a train into dst[m + a*(n + an*(y + ny*xi))]
-__device__ inline void stage_core(double* dst, const double* base, const int32_t* bond, int64_t stride, int L,
+template <class DP>
+__device__ inline void stage_core(DP dst, const gdbl* base, const gint* bond, int64_t stride, int L,
                                   int t, bool mirror, int nyq) {
   const int tp = mirror ? (L - 1 - t) : t;
   const int pl = bond[tp], pr = bond[tp + 1];
   const int a = mirror ? pr : pl, an = mirror ? pl : pr;
-  const double* src = base + (int64_t)tp * stride;
+  const gdbl* src = base + (int64_t)tp * stride;
   const int tot = a * an * nyq;
   for (int idx = threadIdx.x; idx < tot; idx += WG_THREADS) {
     int m = idx % a; int rest = idx / a; int n = rest % an; int s = rest / an;
@@ -41,7 +45,8 @@ __device__ inline void stage_core(double* dst, const double* base, const int32_t
 }
 
 // E_xi[(m2 + b*y) + M2*(n2 + bn*y1)] = sum_y2 pyy[y,y1,y2,xi] * A2c[m2,n2,y2,xi]
-__device__ inline void build_E(double* E, const double* A2c, const double* pyy, int b, int bn, int ny, int ny1,
+template <class DP>
+__device__ inline void build_E(DP E, DP A2c, const gdbl* pyy, int b, int bn, int ny, int ny1,
                                int ny2, int q) {
   const int M2 = b * ny, K2 = bn * ny1;
   const int tot = M2 * K2 * q;
@@ -61,34 +66,44 @@ __device__ inline void atomic_max_double_pos(unsigned long long* addr, double v)
   atomicMax(addr, (unsigned long long)__double_as_longlong(v));
 }
 
-__device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, double* lds, EngStats* stats) {
+// CORES_LDS / JAC_LDS: whether the staged cores + coupling table / the Jacobi matrix live in LDS or in the slot's
+// HBM scratch (decided per launch by the host, plan_cfg); compile-time so that every access has a known address space.
+template <bool CORES_LDS, bool JAC_LDS>
+__device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, double* lds_, EngStats* stats) {
+  typedef typename std::conditional<CORES_LDS, ldbl*, gdbl*>::type CP;
+  typedef typename std::conditional<JAC_LDS, ldbl*, gdbl*>::type JP;
   const int tid = threadIdx.x;
   const int L = cfg.L;
   const bool mirror = P.mirror != 0;
   const int ny1 = P.ny1, ny2 = P.ny2, ny = P.ny, q = P.q;
-  double* ldsG = lds + cfg.lds_gemm;
-  double* ldsQ = lds + cfg.lds_qr;
-  double* misc = lds + cfg.lds_misc;            // [32 + 2*nmax]: reductions, sigma, order
-  double* A1c = cfg.lds_A1c >= 0 ? lds + cfg.lds_A1c : slot + cfg.off_A1c;
-  double* A2c = cfg.lds_A2c >= 0 ? lds + cfg.lds_A2c : slot + cfg.off_A2c;
-  double* E = cfg.lds_E >= 0 ? lds + cfg.lds_E : slot + cfg.off_E;
-  double* JA = cfg.lds_JA >= 0 ? lds + cfg.lds_JA : slot + cfg.off_JA;
-  double* JV = cfg.lds_JV >= 0 ? lds + cfg.lds_JV : slot + cfg.off_JV;
-  int* rdim = reinterpret_cast<int*>(lds + cfg.lds_rdim);   // [L+1]
-  double* red = misc;                        // 32 doubles
-  double* sig = misc + 32;                   // [nmax]
-  int* ord = reinterpret_cast<int*>(misc + 32 + cfg.nmax);   // [nmax]
-  double* LfS = slot + cfg.off_Lf;
-  double* Z = slot + cfg.off_Z;
-  double* Y = slot + cfg.off_Y;
-  double* T1 = slot + cfg.off_T1;
-  double* Nt = slot + cfg.off_Nt;
-  double* Mt = slot + cfg.off_Mt;
-  double* Ccur = slot + cfg.off_C0;
-  double* Cnew = slot + cfg.off_C1;
+  gdbl* slot = (gdbl*)slot_;
+  ldbl* lds = (ldbl*)lds_;
+  ldbl* ldsG = lds + cfg.lds_gemm;
+  ldbl* ldsQ = lds + cfg.lds_qr;
+  ldbl* misc = lds + cfg.lds_misc;              // [32 + 2*nmax]: reductions, sigma, order
+  CP A1c = CORES_LDS ? (CP)(lds + cfg.lds_A1c) : (CP)(slot + cfg.off_A1c);
+  CP A2c = CORES_LDS ? (CP)(lds + cfg.lds_A2c) : (CP)(slot + cfg.off_A2c);
+  CP E = CORES_LDS ? (CP)(lds + cfg.lds_E) : (CP)(slot + cfg.off_E);
+  JP JA = JAC_LDS ? (JP)(lds + cfg.lds_JA) : (JP)(slot + cfg.off_JA);
+  lint* rdim = (lint*)(lds + cfg.lds_rdim);     // [L+1]
+  ldbl* red = misc;                          // 32 doubles
+  ldbl* sig = misc + 32;                     // [nmax]
+  lint* ord = (lint*)(misc + 32 + cfg.nmax);   // [nmax]
+  gdbl* LfS = slot + cfg.off_Lf;
+  gdbl* Z = slot + cfg.off_Z;
+  gdbl* Y = slot + cfg.off_Y;
+  gdbl* T1 = slot + cfg.off_T1;
+  gdbl* Nt = slot + cfg.off_Nt;
+  gdbl* Mt = slot + cfg.off_Mt;
+  gdbl* Ccur = slot + cfg.off_C0;
+  gdbl* Cnew = slot + cfg.off_C1;
+  const gdbl* PA1 = (const gdbl*)P.A1; const gdbl* PA2 = (const gdbl*)P.A2;
+  const gint* Pb1 = (const gint*)P.bond1; const gint* Pb2 = (const gint*)P.bond2;
+  const gdbl* Ppyy = (const gdbl*)P.pyy;
+  gdbl* Pout = (gdbl*)P.out; gint* Pob = (gint*)P.obond;
 
-  auto LB1 = [&](int t) { return mirror ? P.bond1[L - t] : P.bond1[t]; };
-  auto LB2 = [&](int t) { return mirror ? P.bond2[L - t] : P.bond2[t]; };
+  auto LB1 = [&](int t) { return mirror ? Pb1[L - t] : Pb1[t]; };
+  auto LB2 = [&](int t) { return mirror ? Pb2[L - t] : Pb2[t]; };
   auto TP = [&](int t) { return mirror ? (L - 1 - t) : t; };
   Prof* pr = cfg.prof;
   unsigned long long plast = pr ? wall_clock64() : 0ULL;
@@ -101,11 +116,11 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     const int a = LB1(t), an = LB1(t + 1), b = LB2(t), bn = LB2(t + 1);
     const int Bm = a * b, Bn = an * bn;
     const int r1 = rdim[t + 1];
-    const double* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;    // Lf^T: [r1 x Bn], ld r1 (rank index fastest)
-    stage_core(A1c, P.A1, P.bond1, P.stride1, L, t, mirror, ny1 * q);
-    stage_core(A2c, P.A2, P.bond2, P.stride2, L, t, mirror, ny2 * q);
+    const gdbl* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;      // Lf^T: [r1 x Bn], ld r1 (rank index fastest)
+    stage_core(A1c, PA1, Pb1, P.stride1, L, t, mirror, ny1 * q);
+    stage_core(A2c, PA2, Pb2, P.stride2, L, t, mirror, ny2 * q);
     __syncthreads();
-    build_E(E, A2c, P.pyy + (int64_t)TP(t) * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
+    build_E(E, A2c, Ppyy + (int64_t)TP(t) * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
     __syncthreads();
     PROF(PH_STAGE);
     // Every tile index below has the rank index k fastest, so loads and stores are contiguous along k.
@@ -147,17 +162,19 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     const int lane_ = tid & 63, wave_ = tid >> 6;
     double mx = 0.0;
     for (int m = wave_; m < Bm; m += WG_WAVES) {
-      const double* yc = Y + (int64_t)ldY * m;
+      const gdbl* yc = Y + (int64_t)ldY * m;
       const int kend = min(kmax, m + 1);
       for (int k = lane_; k < kend; k += 64) mx = fmax(mx, fabs(yc[k]));
     }
     mx = wg_max(mx, red);
     const double inv = (mx > 0.0 && isfinite(mx)) ? 1.0 / mx : 1.0;
-    double* Lf0 = LfS + (int64_t)t * cfg.lf_stride;                 // Lf^T = R: [kmax x Bm], ld kmax
+    gdbl* Lf0 = LfS + (int64_t)t * cfg.lf_stride;                   // Lf^T = R: [kmax x Bm], ld kmax
     for (int m = wave_; m < Bm; m += WG_WAVES) {
-      const double* yc = Y + (int64_t)ldY * m;
-      double* lc = Lf0 + (int64_t)kmax * m;
-      for (int k = lane_; k < kmax; k += 64) lc[k] = (k <= m) ? yc[k] * inv : 0.0;
+      const gdbl* yc = Y + (int64_t)ldY * m;
+      gdbl* lc = Lf0 + (int64_t)kmax * m;
+      const int kend = min(kmax, m + 1);        // two branch-free loops: a select on the loaded value would
+      for (int k = lane_; k < kend; k += 64) lc[k] = yc[k] * inv;       // turn the load into a branch
+      for (int k = kend + lane_; k < kmax; k += 64) lc[k] = 0.0;
     }
     if (tid == 0) rdim[t] = kmax;
     __syncthreads();
@@ -168,16 +185,16 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
   double logc = 0.0;
   int kc = 1;
   if (tid == 0) Ccur[0] = 1.0;
-  if (tid == 0) { P.obond[mirror ? L : 0] = 1; P.obond[mirror ? 0 : L] = 1; }
+  if (tid == 0) { Pob[mirror ? L : 0] = 1; Pob[mirror ? 0 : L] = 1; }
   __syncthreads();
   for (int t = 0; t < L; t++) {
     const int a = LB1(t), an = LB1(t + 1), b = LB2(t), bn = LB2(t + 1);
     const int Bn = an * bn;
     const int tp = TP(t);
-    stage_core(A1c, P.A1, P.bond1, P.stride1, L, t, mirror, ny1 * q);
-    stage_core(A2c, P.A2, P.bond2, P.stride2, L, t, mirror, ny2 * q);
+    stage_core(A1c, PA1, Pb1, P.stride1, L, t, mirror, ny1 * q);
+    stage_core(A2c, PA2, Pb2, P.stride2, L, t, mirror, ny2 * q);
     __syncthreads();
-    build_E(E, A2c, P.pyy + (int64_t)tp * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
+    build_E(E, A2c, Ppyy + (int64_t)tp * P.pyy_tstride, b, bn, ny, ny1, ny2, q);
     __syncthreads();
     PROF(PH_STAGE);
     // N1: T1[(k,m2) ; (n1,y1,xi)] = sum_m1 A1[m1,n1,y1,xi] C[k,(m1,m2)]        T1[j + kc*b*i], j = k + kc*m2
@@ -214,7 +231,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
       __syncthreads();
     }
     PROF(PH_N);
-    double* oc = P.out + (int64_t)tp * P.ostride;
+    gdbl* oc = Pout + (int64_t)tp * P.ostride;
     if (t == L - 1) {
       // last core: [kc, 1, s] = Nt[(k,s), 0]
       for (int idx = tid; idx < Rr; idx += WG_THREADS) {
@@ -226,7 +243,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
       break;
     }
     const int r1 = rdim[t + 1];
-    const double* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;
+    const gdbl* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;
     // Mt^T [r1 x Rr] = Lf1^T Nt^T
     const int ldM = r32(r1);
     const int Rr16 = r16(Rr) + 16;
@@ -255,13 +272,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
     }
     fro2 = wg_sum(fro2, red);
     __syncthreads();
-    int sw;
-    {
-      ldbl* redl = (ldbl*)red;
-      __attribute__((address_space(3))) int* ordl = (__attribute__((address_space(3))) int*)ord;
-      sw = (cfg.lds_JA >= 0) ? jacobi_rsv((ldbl*)JA, ldJ, Rr, k2, nullptr, 0, redl, ordl, 60)
-                             : jacobi_rsv((gdbl*)JA, ldJ, Rr, k2, nullptr, 0, redl, ordl, 60);
-    }
+    const int sw = jacobi_rsv(JA, ldJ, Rr, k2, nullptr, 0, red, ord, 60);
     if (tid == 0) {
       if (sw < 0) stats->jacobi_fail = 1;
       atomicAdd(&stats->jac_sweeps, (unsigned long long)(sw < 0 ? 60 : sw));
@@ -323,13 +334,13 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
                            : ((int64_t)k + (int64_t)kc * (k2i + (int64_t)kp * s));
       oc[off] = v;
     }
-    if (tid == 0) P.obond[mirror ? (L - (t + 1)) : (t + 1)] = kp;
+    if (tid == 0) Pob[mirror ? (L - (t + 1)) : (t + 1)] = kp;
     PROF(PH_TRUNC);
     // carry C' [kp x Bn] = U^T Nt
     gemm_direct(kp, Bn, Rr, JA, [=](int i) { return (int64_t)ldJ * ord[i]; }, [=](int kk) { return kk; },
          Nt, [=](int kk) { return kk; }, [=](int j) { return (int64_t)Rr * j; },
          Cnew, [=](int i) { return i; }, [=](int j) { return (int64_t)kp * j; }, false);
-    double* tmp = Ccur; Ccur = Cnew; Cnew = tmp;
+    gdbl* tmp = Ccur; Ccur = Cnew; Cnew = tmp;
     kc = kp;
     PROF(PH_CARRY);
   }
@@ -338,8 +349,8 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot, d
   double logz = (P.logz1 ? *P.logz1 : 0.0) + (P.logz2 ? *P.logz2 : 0.0) - logc;
   __syncthreads();
   for (int tp = 0; tp < L; tp++) {
-    const int n = P.obond[tp] * P.obond[tp + 1] * ny * q;
-    double* oc = P.out + (int64_t)tp * P.ostride;
+    const int n = Pob[tp] * Pob[tp + 1] * ny * q;
+    gdbl* oc = Pout + (int64_t)tp * P.ostride;
     double mx = 0.0;
     for (int idx = tid; idx < n; idx += WG_THREADS) mx = fmax(mx, fabs(oc[idx]));
     mx = wg_max(mx, red);

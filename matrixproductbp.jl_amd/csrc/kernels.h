@@ -24,7 +24,13 @@
       const int p = s_p;                                                                                          \
       __syncthreads();                                                                                            \
       if (p >= nprob) break;                                                                                      \
-      eng::run_problem(probs[p], cfg, slot, lds, stats);                                                          \
+      if (cfg.lds_A1c >= 0) {                                                                                     \
+        if (cfg.lds_JA >= 0) eng::run_problem<true, true>(probs[p], cfg, slot, lds, stats);                       \
+        else eng::run_problem<true, false>(probs[p], cfg, slot, lds, stats);                                      \
+      } else {                                                                                                    \
+        if (cfg.lds_JA >= 0) eng::run_problem<false, true>(probs[p], cfg, slot, lds, stats);                      \
+        else eng::run_problem<false, false>(probs[p], cfg, slot, lds, stats);                                     \
+      }                                                                                                           \
     }                                                                                                             \
   }                                                                                                               \
   /* self-test / microbenchmark: Hestenes Jacobi on a pseudo-random m x n matrix held in LDS */                   \
@@ -453,14 +459,15 @@ __global__ void pair_kernel(const PairProb* probs, int L) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WG_THREADS) st_gemm_kernel(int M, int N, int K, const double* A, const double* B, double* C) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  wg::gemm(M, N, K, A, [=](int i) { return i; }, [=](int k) { return (int64_t)M * k; },
-           B, [=](int k) { return k; }, [=](int j) { return (int64_t)K * j; }, true,
-           C, [=](int i) { return i; }, [=](int j) { return (int64_t)M * j; }, false, lds);
+  wg::gemm(M, N, K, (const gdbl*)A, [=](int i) { return i; }, [=](int k) { return (int64_t)M * k; },
+           (const gdbl*)B, [=](int k) { return k; }, [=](int j) { return (int64_t)K * j; }, true,
+           (gdbl*)C, [=](int i) { return i; }, [=](int j) { return (int64_t)M * j; }, false, (ldbl*)lds);
 }
 __global__ void __launch_bounds__(WG_THREADS) st_qr_kernel(double* Y, int ld, int rows, int cols, wg::Prof* pr) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   unsigned long long last = pr ? wall_clock64() : 0ULL;
-  wg::qr_r(Y + (int64_t)blockIdx.x * ld * (((cols + 15) & ~15) + 16), ld, rows, cols, lds, lds + wg::QR_LDS_DOUBLES,
+  wg::qr_r((gdbl*)Y + (int64_t)blockIdx.x * ld * (((cols + 15) & ~15) + 16), ld, rows, cols, (ldbl*)lds,
+           (ldbl*)lds + wg::QR_LDS_DOUBLES,
            pr, &last, -1, -1);
 }
 __global__ void __launch_bounds__(WG_THREADS) st_svd_kernel(double* A, int m, int n, double* V, double* sigma, int* sweeps) {

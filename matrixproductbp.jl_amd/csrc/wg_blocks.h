@@ -26,9 +26,9 @@ constexpr int GM_LDA = 112;  // LDS leading dims: == 16 (mod 32) doubles so that
 constexpr int GM_LDB = 144;  // ds_read_b64 half-wave land on disjoint banks
 constexpr int GM_LDS_DOUBLES = GM_KC * (GM_LDA + GM_LDB);   // 4096 doubles = 32 KiB
 
-template <class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
-__device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, const double* Sp, SRO sro, SCO sco,
-                                                     const double* Xp, XRO xro, XCO xco, double* Op, ORO oro, OCO oco,
+template <class SP, class XP, class OP, class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
+__device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp, SRO sro, SCO sco,
+                                                     XP Xp, XRO xro, XCO xco, OP Op, ORO oro, OCO oco,
                                                      bool accumulate);
 
 // O(i,j) (+)= sum_k S(i,k) X(k,j),  i<M, j<N, k<K.
@@ -36,8 +36,8 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, const
 // `xkfast`: X is contiguous along k (else along j) - only picks the coalesced staging pattern.
 // `lds` must provide GM_LDS_DOUBLES doubles.  Ends with a __syncthreads().
 template <class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
-__device__ void gemm(int M, int N, int K, const double* Sp, SRO sro, SCO sco, const double* Xp, XRO xro,
-                     XCO xco, bool xkfast, double* Op, ORO oro, OCO oco, bool accumulate, double* lds) {
+__device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* Sp, SRO sro, SCO sco, const gdbl* Xp, XRO xro,
+                     XCO xco, bool xkfast, gdbl* Op, ORO oro, OCO oco, bool accumulate, ldbl* lds) {
 #if WG_THREADS != 512
   // the LDS staging maps below are laid out for 512 threads; smaller workgroups take the barrier-free form
   (void)xkfast; (void)lds;
@@ -46,8 +46,8 @@ __device__ void gemm(int M, int N, int K, const double* Sp, SRO sro, SCO sco, co
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  double* As = lds;
-  double* Bs = lds + GM_KC * GM_LDA;
+  ldbl* As = lds;
+  ldbl* Bs = lds + GM_KC * GM_LDA;
   for (int mb = 0; mb < M; mb += GM_MB) {
     const int mrows = min(GM_MB, M - mb);
     const int ntm = (mrows + 15) >> 4;
@@ -139,7 +139,7 @@ __device__ void gemm(int M, int N, int K, const double* Sp, SRO sro, SCO sco, co
               for (int r = 0; r < 4; r++) {
                 int row = t * 16 + g + 4 * r;
                 if (row < mrows) {
-                  double* p = Op + (long)oro(mb + row) + oc;
+                  gdbl* p = Op + (long)oro(mb + row) + oc;
                   double v = acc[t][r];
                   if (accumulate) v += *p;
                   *p = v;
@@ -160,9 +160,10 @@ __device__ void gemm(int M, int N, int K, const double* Sp, SRO sro, SCO sco, co
 // fragments straight from global memory (8 B per lane per k-step, all k-steps of a tile in flight together)
 // and its A fragments from wherever S lives.  No LDS staging, no __syncthreads() inside; waves never wait for
 // each other.  Same index-map interface as gemm().  Ends with a __syncthreads().
-template <class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
-__device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, const double* Sp, SRO sro, SCO sco,
-                                                     const double* Xp, XRO xro, XCO xco, double* Op, ORO oro, OCO oco,
+// SP / XP / OP are address-space typed pointers (ldbl* or gdbl*, see wg_common.h).
+template <class SP, class XP, class OP, class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
+__device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp, SRO sro, SCO sco,
+                                                     XP Xp, XRO xro, XCO xco, OP Op, ORO oro, OCO oco,
                                                      bool accumulate) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -220,7 +221,7 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, const
             for (int r = 0; r < 4; r++) {
               const int row = t * 16 + g + 4 * r;
               if (row < mrows) {
-                double* p = Op + (long)oro(mb + row) + oc;
+                OP p = Op + (long)oro(mb + row) + oc;
                 double v = acc[t][r];
                 if (accumulate) v += *p;
                 *p = v;
@@ -270,10 +271,6 @@ __device__ __forceinline__ double wg_max(double v, ldbl* red) {
   return s;
 }
 
-// `red` is always LDS scratch; callers that still hold it as a generic pointer go through these
-__device__ __forceinline__ double wg_sum(double v, double* red) { return wg_sum(v, (ldbl*)red); }
-__device__ __forceinline__ double wg_max(double v, double* red) { return wg_max(v, (ldbl*)red); }
-
 // max |x| over a strided 2D region (rows x cols, leading dim ld); all threads get it
 template <class AP>
 __device__ inline double wg_maxabs(AP A, long ld, int rows, int cols, ldbl* red) {
@@ -286,9 +283,6 @@ __device__ inline double wg_maxabs(AP A, long ld, int rows, int cols, ldbl* red)
   }
   return wg_max(m, red);
 }
-
-template <class AP>
-__device__ inline double wg_maxabs(AP A, long ld, int rows, int cols, double* red) { return wg_maxabs(A, ld, rows, cols, (ldbl*)red); }
 
 // ---------------------------------------------------------------------------------------------
 // Blocked Householder QR, R only, in place.
@@ -924,11 +918,8 @@ __device__ __forceinline__ void qr_tile_update_all(gdbl* Y, long ld, int rows32,
 }
 
 // `big`: >= WG_WAVES*512 doubles of LDS scratch (may alias the gemm tile buffers)
-__device__ void qr_r(double* Y_, long ld, int rows, int cols, double* lds_, double* big_, Prof* pr = nullptr,
+__device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
-  gdbl* Y = (gdbl*)Y_;                  // the matrix lives in HBM, the scratch in LDS: say so (see wg_common.h)
-  ldbl* lds = (ldbl*)lds_;
-  ldbl* big = (ldbl*)big_;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   ldbl* red = lds;                      // [WG_WAVES*16]
