@@ -211,8 +211,16 @@ def main():
         ex = fl["executed_ops"] * n_local * args.steps
         refalg = fl["reference_ops"] * n_local * args.steps
         achieved = ex / t_orth / 1e12 if t_orth > 0 else 0.0
+        # HBM-side bytes per launch come from the committed rocprofv3 --pmc passes of this same command
+        # (bench.py cannot run the profiler on itself); only quoted for the configuration they were taken on
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_eng_kernel.json")
+        if world == 1 and (N, T, Mb) == (1024, 50, 20) and os.path.exists(pmc):
+            with open(pmc) as fh:
+                traffic = json.load(fh)["bytes_per_launch_avg"]
+            traffic_src = "profiles/r01_pmc_eng_kernel.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "eng_kernel (cavity op levels)", "launches": launches,
                     "avg_launch_ms": (t_orth / launches * 1e3) if launches else None,
                     "flops_per_launch_executed": ex / launches if launches else None,

@@ -304,7 +304,9 @@ constexpr int QR_NB = 16;
 constexpr int QR_RS = 4;      // rows per thread of the register panel
 constexpr int QR_TC = 3;      // column tiles a wave updates together
 constexpr int QR_LDS_BASE = WG_WAVES * 16 + 16 * 16 + 16 + 2 * 32 + 2 * 16;
-constexpr int QR_LDS_DOUBLES = QR_LDS_BASE + 256 + 256 + 16;
+constexpr bool QR_QUAD = (WG_THREADS == 512);   // aggregate four panels (K = 64 trailing updates) - 512-thread variant only
+constexpr int QR_LDS_PAIR = QR_LDS_BASE + 256 + 256 + 16;
+constexpr int QR_LDS_DOUBLES = QR_LDS_PAIR + (QR_QUAD ? 7 * 256 + 32 : 0);
 
 // 16 per-lane partial values -> lanes with (lane & 3) == 0 hold the wave total of value
 // idx = ((lane>>5)&1)<<3 | ((lane>>4)&1)<<2 | ((lane>>3)&1)<<1 | ((lane>>2)&1)   (17 shuffles instead of 96)
@@ -917,6 +919,215 @@ __device__ __forceinline__ void qr_tile_update_all(gdbl* Y, long ld, int rows32,
   __syncthreads();
 }
 
+// Update ONE 16-column tile (first column cb0) by the panel PAIR a (j0), b (j0+16) with all waves working on
+// different rows (the row-parallel counterpart of qr_trail2<1>): partial Va^T C, Vb^T C -> LDS, then every wave
+// forms Wa, Wb and applies them to its own 32-row stages.  `big`: WG_WAVES*512 doubles.
+__device__ __forceinline__ void qr_tile_update2_all(gdbl* Y, long ld, int rows32, int j0, int cb0, const ldbl* TsA,
+                                                    const ldbl* TsB, const ldbl* Sm, ldbl* big) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nrb = (rows32 - j0) >> 4;
+  const gdbl* vacol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
+  const gdbl* vbcol = Y + (long)(j0 + 16 + l15) * ld + j0 + 4 * g;
+  const gdbl* ccol = Y + (long)(cb0 + l15) * ld + j0 + 4 * g;
+  d4 acca = d4{0, 0, 0, 0}, accb = d4{0, 0, 0, 0};
+  for (int rb = wave; rb < nrb; rb += WG_WAVES) {
+    d4 va = *reinterpret_cast<const gd4*>(vacol + 16 * rb);
+    d4 vb = *reinterpret_cast<const gd4*>(vbcol + 16 * rb);
+    d4 c = *reinterpret_cast<const gd4*>(ccol + 16 * rb);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rho = 4 * g + e;
+      double a = va[e], b = vb[e];
+      a = (rb == 0) ? ((rho > l15) ? a : ((rho == l15) ? 1.0 : 0.0)) : a;
+      b = (rb == 1) ? ((rho > l15) ? b : ((rho == l15) ? 1.0 : 0.0)) : b;
+      va[e] = a;
+      vb[e] = (rb >= 1) ? b : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) { acca = mfma(va[e], c[e], acca); accb = mfma(vb[e], c[e], accb); }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    big[wave * 512 + (g + 4 * r) + 16 * l15] = acca[r];
+    big[wave * 512 + 256 + (g + 4 * r) + 16 * l15] = accb[r];
+  }
+  __syncthreads();
+  d4 wa0 = d4{0, 0, 0, 0}, wb0 = d4{0, 0, 0, 0};
+#pragma unroll
+  for (int w = 0; w < WG_WAVES; w++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      wa0[r] += big[w * 512 + (g + 4 * r) + 16 * l15];
+      wb0[r] += big[w * 512 + 256 + (g + 4 * r) + 16 * l15];
+    }
+  d4 wa = d4{0, 0, 0, 0}, wb = d4{0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 4; s++) wa = mfma(TsA[(4 * s + g) + 16 * l15], wa0[s], wa);
+  d4 t = wb0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) t = mfma(-Sm[l15 + 16 * (4 * s + g)], wa[s], t);
+#pragma unroll
+  for (int s = 0; s < 4; s++) wb = mfma(TsB[(4 * s + g) + 16 * l15], t[s], wb);
+  const int jb = j0 & ~31;
+  const int nst = (rows32 - jb) >> 5;
+  for (int st = wave; st < nst; st += WG_WAVES) {
+    const int row = jb + 32 * st + 2 * l15;
+    d2 va[4], vb[4], c[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) {
+      const int k = 4 * s2 + g;
+      d2 xa = *reinterpret_cast<const gd2*>(Y + (long)(j0 + k) * ld + row);
+      d2 xb = *reinterpret_cast<const gd2*>(Y + (long)(j0 + 16 + k) * ld + row);
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int ra = row + e - j0, rbb = row + e - j0 - 16;
+        double a = xa[e], b = xb[e];
+        a = (ra < 16) ? ((ra > k) ? a : ((ra == k) ? 1.0 : 0.0)) : a;
+        b = (rbb < 16) ? ((rbb > k) ? b : ((rbb == k) ? 1.0 : 0.0)) : b;
+        xa[e] = (ra >= 0) ? a : 0.0;
+        xb[e] = (rbb >= 0) ? b : 0.0;
+      }
+      va[s2] = xa; vb[s2] = xb;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      d4 acc = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) { acc = mfma(-wa[s2], va[s2][e], acc); acc = mfma(-wb[s2], vb[s2][e], acc); }
+#pragma unroll
+      for (int r = 0; r < 4; r++) c[r][e] = acc[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) *reinterpret_cast<gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row) = c[r];
+  }
+  __syncthreads();
+}
+
+// Trailing update by FOUR adjacent full panels p = 0..3 (columns j0 + 16p) in one pass over the rows - a quarter of
+// the HBM traffic of four single-panel passes:
+//   C <- C - sum_p V_p W_p,   W_p = T_p^T (V_p^T C - sum_{r<p} S_pr W_r),   S_pr = V_p^T V_r  (16x16 blocks in LDS).
+// Tq[p] = T_p; Sq = {S10, S20, S21, S30, S31, S32}.
+template <int NT>
+__device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, int cb0, const ldbl* const (&Tq)[4],
+                                          const ldbl* const (&Sq)[6]) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nrb = (rows32 - j0) >> 4;
+  const gdbl* vcol[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) vcol[p] = Y + (long)(j0 + 16 * p + l15) * ld + j0 + 4 * g;
+  const gdbl* ccol[NT];
+  d4 w0[4][NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    ccol[q] = Y + (long)(cb0 + 16 * q + l15) * ld + j0 + 4 * g;
+#pragma unroll
+    for (int p = 0; p < 4; p++) w0[p][q] = d4{0, 0, 0, 0};
+  }
+  // ---- phase A: W0_p = V_p^T C  (2-stage register ring: the next row block is in flight behind the MFMAs)
+  {
+    d4 sv[2][4], sc[2][NT];
+    auto loadA = [&](int rb, d4 (&v)[4], d4 (&c)[NT]) {
+      const int rbc = min(rb, nrb - 1);
+#pragma unroll
+      for (int p = 0; p < 4; p++) v[p] = *reinterpret_cast<const gd4*>(vcol[p] + 16 * rbc);
+#pragma unroll
+      for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const gd4*>(ccol[q] + 16 * rbc);
+      const bool in = rb < nrb;
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int rho = 4 * g + e;
+          double a = v[p][e];
+          a = (rb == p) ? ((rho > l15) ? a : ((rho == l15) ? 1.0 : 0.0)) : a;   // unit lower-trapezoidal head
+          v[p][e] = (in && rb >= p) ? a : 0.0;
+        }
+    };
+    auto compA = [&](const d4 (&v)[4], const d4 (&c)[NT]) {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+#pragma unroll
+          for (int p = 0; p < 4; p++) w0[p][q] = mfma(v[p][e], c[q][e], w0[p][q]);
+    };
+    loadA(0, sv[0], sc[0]);
+    for (int rb = 0; rb < nrb; rb += 2) {
+      loadA(rb + 1, sv[1], sc[1]); compA(sv[0], sc[0]);
+      loadA(rb + 2, sv[0], sc[0]); compA(sv[1], sc[1]);
+    }
+  }
+  // ---- phase B: the W recurrence, tile by tile, in registers (T and S fragments from LDS)
+  d4 w[4][NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      d4 t = w0[p][q];
+#pragma unroll
+      for (int r = 0; r < p; r++) {
+        const ldbl* S = Sq[p * (p - 1) / 2 + r];
+#pragma unroll
+        for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
+      }
+      d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) o = mfma(Tq[p][(4 * s + g) + 16 * l15], t[s], o);
+      w[p][q] = o;
+    }
+  }
+  // ---- phase C: C^T -= sum_p W_p^T V_p^T over 32-row stages (every access a full 128-B line per column)
+  {
+    const int jb = j0 & ~31;
+    const int nst = (rows32 - jb) >> 5;
+    for (int st = 0; st < nst; st++) {
+      const int row = jb + 32 * st + 2 * l15;
+      d2 v[4][4];
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+          const int k = 4 * s2 + g;
+          d2 x = *reinterpret_cast<const gd2*>(Y + (long)(j0 + 16 * p + k) * ld + row);
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const int rp = row + e - j0 - 16 * p;          // row relative to panel p's diagonal block
+            double a = x[e];
+            a = (rp < 16) ? ((rp > k) ? a : ((rp == k) ? 1.0 : 0.0)) : a;
+            x[e] = (rp >= 0) ? a : 0.0;
+          }
+          v[p][s2] = x;
+        }
+      d2 c[NT][4];
+#pragma unroll
+      for (int q = 0; q < NT; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          c[q][r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
+#pragma unroll
+      for (int q = 0; q < NT; q++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          d4 acc = d4{c[q][0][e], c[q][1][e], c[q][2][e], c[q][3][e]};
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc = mfma(-w[p][q][s2], v[p][s2][e], acc);
+#pragma unroll
+          for (int r = 0; r < 4; r++) c[q][r][e] = acc[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          *reinterpret_cast<gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[q][r];
+      }
+    }
+  }
+}
+
 // `big`: >= WG_WAVES*512 doubles of LDS scratch (may alias the gemm tile buffers)
 __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
@@ -934,53 +1145,107 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
   ldbl* TsB = lds + QR_LDS_BASE;        // second T and the cross Gram S of a panel pair
   ldbl* Sm = TsB + 256;
   ldbl* tauB = Sm + 256;
-  const int ncol16 = (cols + 15) >> 4;
-  (void)rows16;
+  // quad aggregation (QR_QUAD): T of panels c, d, the six cross Grams, their taus
+  ldbl* TsC = lds + QR_LDS_PAIR;
+  ldbl* TsD = TsC + 256;
+  ldbl* Sdc = TsD + 256;
+  ldbl* Sca = Sdc + 256;
+  ldbl* Scb = Sca + 256;
+  ldbl* Sda = Scb + 256;
+  ldbl* Sdb = Sda + 256;
+  ldbl* tauC = Sdb + 256;
+  ldbl* tauD = tauC + 16;
+
+  // factor the full-width register panel at jp: V in place, T -> Tp (taus -> taup)
+  auto factor_panel = [&](int jp, int nbp, ldbl* Tp, ldbl* taup) {
+    for (int i = tid; i < 256; i += WG_THREADS) Tp[i] = 0.0;
+    if (tid < 16) taup[tid] = 0.0;
+    __syncthreads();
+    qr_panel_regs(Y, ld, rows, jp, nbp, red, taup, bc);
+    if (fine) prof_mark(pr, *plast, 14);
+  };
+  // panels (jp, jp+16), both full and register resident: T1, T2 and S21 = V2^T V1
+  auto factor_pair = [&](int jp, ldbl* T1, ldbl* tau1, ldbl* T2, ldbl* tau2, ldbl* S21) {
+    factor_panel(jp, 16, T1, tau1);
+    qr_gram<false>(Y, ld, rows32, jp, jp, 16, jp, 16, jp, 16, big);
+    if (fine) prof_mark(pr, *plast, 15);
+    qr_T_from_gram(big, tau1, 16, T1);
+    if (pr) prof_mark(pr, *plast, fine ? 16 : ph_panel);
+    qr_tile_update_all(Y, ld, rows32, jp, 16, jp + 16, T1, big);
+    if (pr) prof_mark(pr, *plast, fine ? 17 : ph_trail);
+    factor_panel(jp + 16, 16, T2, tau2);
+    qr_gram<true>(Y, ld, rows32, jp, jp + 16, 16, jp + 16, 16, jp, 16, big);   // V2^T V2 and S21 = V2^T V1 in one pass
+    for (int i = tid; i < 256; i += WG_THREADS) S21[i] = big[256 + i];
+    if (fine) prof_mark(pr, *plast, 15);
+    qr_T_from_gram(big, tau2, 16, T2);
+    if (pr) prof_mark(pr, *plast, fine ? 16 : ph_panel);
+  };
+  // tiles [cstart, cols) are shared out to the waves in contiguous runs
+  auto wave_tiles = [&](int cstart, int& tstart, int& tcnt) {
+    const int ntl = (cols - cstart + 15) / 16;   // may be 0
+    const int tbase = ntl / WG_WAVES, trem = ntl % WG_WAVES;
+    tcnt = tbase + (wave < trem ? 1 : 0);
+    tstart = wave * tbase + min(wave, trem);
+  };
+
   for (int j0 = 0; j0 < kmax;) {
     const int nb = min(QR_NB, kmax - j0);
     const bool fast = !force_generic && rows - j0 <= QR_RS * WG_THREADS;
-    for (int i = tid; i < 256; i += WG_THREADS) Ts[i] = 0.0;
-    if (tid < 16) tau[tid] = 0.0;
-    __syncthreads();
-    if (fast) {
-      qr_panel_regs(Y, ld, rows, j0, nb, red, tau, bc);
-      if (fine) prof_mark(pr, *plast, 14);
-      qr_gram<false>(Y, ld, rows32, j0, j0, nb, j0, nb, j0, nb, big);
-      if (fine) prof_mark(pr, *plast, 15);
-      qr_T_from_gram(big, tau, nb, Ts);
-      if (fine) prof_mark(pr, *plast, 16);
-    } else qr_panel_global(Y, ld, rows, j0, nb, red, Ts, tau, bc);
-    // pair with the next panel when both are full-width register panels and a trailing matrix remains
-    const int j1 = j0 + 16;
-    const int nbb = min(QR_NB, kmax - j1);
-    const bool pair = fast && nb == 16 && j1 < kmax && nbb == 16 && (j1 + 16 < cols);
-    if (pr && !fine) prof_mark(pr, *plast, ph_panel);
-    if (pair) {
-      qr_tile_update_all(Y, ld, rows32, j0, 16, j1, Ts, big);
+    // four / two full register panels with a trailing matrix behind them are aggregated
+    const bool quad = QR_QUAD && fast && j0 + 64 <= kmax && j0 + 64 < cols;
+    const bool pair = !quad && fast && j0 + 32 <= kmax && j0 + 32 < cols;
+    if (quad) {
+      factor_pair(j0, Ts, tau, TsB, tauB, Sm);
+      qr_tile_update2_all(Y, ld, rows32, j0, j0 + 32, Ts, TsB, Sm, big);
+      qr_tile_update2_all(Y, ld, rows32, j0, j0 + 48, Ts, TsB, Sm, big);
       if (pr) prof_mark(pr, *plast, fine ? 17 : ph_trail);
-      if (tid < 16) tauB[tid] = 0.0;
+      factor_pair(j0 + 32, TsC, tauC, TsD, tauD, Sdc);
+      qr_gram<true>(Y, ld, rows32, j0 + 32, j0 + 32, 16, j0, 16, j0 + 16, 16, big);       // Sca, Scb
+      for (int i = tid; i < 256; i += WG_THREADS) { Sca[i] = big[i]; Scb[i] = big[256 + i]; }
       __syncthreads();
-      qr_panel_regs(Y, ld, rows, j1, nbb, red, tauB, bc);
-      if (fine) prof_mark(pr, *plast, 14);
-      qr_gram<true>(Y, ld, rows32, j0, j1, nbb, j1, nbb, j0, 16, big);   // Vb^T Vb and S = Vb^T Va in one pass
-      for (int i = tid; i < 256; i += WG_THREADS) Sm[i] = big[256 + i];
-      if (fine) prof_mark(pr, *plast, 15);
-      qr_T_from_gram(big, tauB, nbb, TsB);
+      qr_gram<true>(Y, ld, rows32, j0 + 48, j0 + 48, 16, j0, 16, j0 + 16, 16, big);       // Sda, Sdb
+      for (int i = tid; i < 256; i += WG_THREADS) { Sda[i] = big[i]; Sdb[i] = big[256 + i]; }
+      __syncthreads();
+      if (pr) prof_mark(pr, *plast, fine ? 15 : ph_panel);
+      const ldbl* const Tq[4] = {Ts, TsB, TsC, TsD};
+      const ldbl* const Sq[6] = {Sm, Sca, Scb, Sda, Sdb, Sdc};
+      int tstart, tcnt;
+      wave_tiles(j0 + 64, tstart, tcnt);
+      for (int tg = 0; tg < tcnt; tg += 2) {
+        const int cb0 = j0 + 64 + (tstart + tg) * 16;
+        if (tcnt - tg >= 2) qr_trail4<2>(Y, ld, rows32, j0, cb0, Tq, Sq);
+        else qr_trail4<1>(Y, ld, rows32, j0, cb0, Tq, Sq);
+      }
+      __syncthreads();
+      if (pr) prof_mark(pr, *plast, fine ? 18 : ph_trail);
+      j0 += 64;
+      continue;
+    }
+    if (pair) factor_pair(j0, Ts, tau, TsB, tauB, Sm);
+    else {
+      for (int i = tid; i < 256; i += WG_THREADS) Ts[i] = 0.0;
+      if (tid < 16) tau[tid] = 0.0;
+      __syncthreads();
+      if (fast) {
+        qr_panel_regs(Y, ld, rows, j0, nb, red, tau, bc);
+        if (fine) prof_mark(pr, *plast, 14);
+        qr_gram<false>(Y, ld, rows32, j0, j0, nb, j0, nb, j0, nb, big);
+        if (fine) prof_mark(pr, *plast, 15);
+        qr_T_from_gram(big, tau, nb, Ts);
+      } else qr_panel_global(Y, ld, rows, j0, nb, red, Ts, tau, bc);
       if (pr) prof_mark(pr, *plast, fine ? 16 : ph_panel);
     }
     // ------------------------------------------------------------------ trailing update
-    const int cstart = pair ? j1 + 16 : j0 + nb;
-    const int ntl = (cols - cstart + 15) / 16;   // tiles of 16 columns starting at cstart (may be 0)
-    const int tbase = ntl / WG_WAVES, trem = ntl % WG_WAVES;
-    const int tcnt = tbase + (wave < trem ? 1 : 0);
-    const int tstart = wave * tbase + min(wave, trem);
+    const int cstart = pair ? j0 + 32 : j0 + nb;
+    int tstart, tcnt;
+    wave_tiles(cstart, tstart, tcnt);
     for (int tg = 0; tg < tcnt; tg += QR_TC) {
       const int nt = min(QR_TC, tcnt - tg);
       const int cb0 = cstart + (tstart + tg) * 16;
       if (pair) {
-        if (nt == 1) qr_trail2<1>(Y, ld, rows32, j0, nbb, cb0, Ts, TsB, Sm);
-        else if (nt == 2) qr_trail2<2>(Y, ld, rows32, j0, nbb, cb0, Ts, TsB, Sm);
-        else qr_trail2<3>(Y, ld, rows32, j0, nbb, cb0, Ts, TsB, Sm);
+        if (nt == 1) qr_trail2<1>(Y, ld, rows32, j0, 16, cb0, Ts, TsB, Sm);
+        else if (nt == 2) qr_trail2<2>(Y, ld, rows32, j0, 16, cb0, Ts, TsB, Sm);
+        else qr_trail2<3>(Y, ld, rows32, j0, 16, cb0, Ts, TsB, Sm);
       } else {
         if (nt == 1) qr_trail<1>(Y, ld, rows32, j0, nb, cb0, Ts);
         else if (nt == 2) qr_trail<2>(Y, ld, rows32, j0, nb, cb0, Ts);
@@ -991,7 +1256,7 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
     if (pr) prof_mark(pr, *plast, fine ? 18 : ph_trail);
     j0 += pair ? 32 : 16;
   }
-  (void)ncol16;
+  (void)g; (void)l15; (void)lane;
 }
 
 // ---------------------------------------------------------------------------------------------
