@@ -489,11 +489,9 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   const int64_t nE = (int64_t)pl.q * pl.cap2 * pl.ny * pl.cap2 * pl.ny1;
   cfg.off_A1c = take(nA1); cfg.off_A2c = take(nA2); cfg.off_E = take(nE);
   cfg.slot_doubles = off;
-  // LDS: [gemm][qr][misc][rdim] fixed, then union{cores+E, jacobi} if they fit in 150 KiB
+  // LDS: [qr][misc][rdim] fixed, then union{gemm tiles / QR scratch, cores+E, jacobi} (the last two if they fit)
   int64_t l = 0;
   auto ltake = [&](int64_t n) { int64_t o = l; l += (n + 3) & ~int64_t(3); return (int32_t)o; };
-  // the gemm region doubles as the QR's `big` scratch (WG_WAVES*512 doubles)
-  cfg.lds_gemm = ltake(pl.small ? 512 : v512::wg::GM_LDS_DOUBLES);
   cfg.lds_qr = ltake(pl.small ? v64::wg::QR_LDS_DOUBLES : v512::wg::QR_LDS_DOUBLES);
   cfg.lds_misc = ltake(32 + nmax + (nmax + 1) / 2 + 4);
   cfg.lds_rdim = ltake((L + 2 + 1) / 2 + 2);
@@ -513,7 +511,11 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   else { cfg.lds_A1c = cfg.lds_A2c = cfg.lds_E = -1; }
   if (jac_fit) { cfg.lds_JA = (int32_t)base; cfg.lds_JV = -1; }
   else { cfg.lds_JA = cfg.lds_JV = -1; }
-  int64_t top = base + std::max(cores_fit ? coresE : 0, jac_fit ? jac : 0);
+  // the gemm tiles (which double as the QR's `big` scratch, WG_WAVES*512 doubles) share the same region: within a
+  // time step the staged cores / E are dead once Y_t (sweep 1) or N_t (sweep 2) is built, before any gemm / QR
+  const int64_t gemm_d = pl.small ? 512 : v512::wg::GM_LDS_DOUBLES;
+  cfg.lds_gemm = (int32_t)base;
+  int64_t top = base + std::max(gemm_d, std::max(cores_fit ? coresE : 0, jac_fit ? jac : 0));
   lds_bytes = (size_t)top * 8;
 }
 
