@@ -714,14 +714,26 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
   }
-  // ---------------------------------------------------------------- cavity ops, level by level
-  for (int lev = 1; lev <= maxlevel; lev++) {
-    EngLaunchPlan plb, pls; plb.q = pls.q = q; plb.capout = pls.capout = cap; pls.small = true;
-    for (const OpRec& o : ops) {
-      if (o.level != lev) continue;
+  // ---------------------------------------------------------------- cavity ops
+  // The single-wave problems go level by level.  The 512-thread problems are packed into launches by readiness
+  // rather than by level: a launch takes the problems whose inputs exist, cut to a whole number of rounds of the
+  // resident workgroups when more are ready (problems that others wait for first), so that a rank with few nodes
+  // (128 nodes: 128 + 384 problems in two levels) fills the CUs in 2 rounds instead of 1 + 2 half-empty ones.
+  // This needs the 512-thread problems to read single-wave results of level 1 only (products with the bond-1
+  // initial train) - checked, with the plain level-by-level order as the fallback.
+  {
+    auto is_small = [&](const OpRec& o) { return small_problem((int64_t)tr[o.in1].cap * tr[o.in2].cap, tr[o.out].ny, q); };
+    std::vector<char> train_small(specs.size(), 0), avail(specs.size(), 1);
+    std::vector<int> train_level(specs.size(), 0);
+    bool pack_ok = getenv("MPBP_DEBUG_NO_PACK") == nullptr;
+    for (const OpRec& o : ops) { train_small[o.out] = is_small(o) ? 1 : 0; train_level[o.out] = o.level; avail[o.out] = 0; }
+    for (const OpRec& o : ops)
+      if (!is_small(o))
+        for (int in : {o.in1, o.in2})
+          if (train_level[in] > 1 && train_small[in]) pack_ok = false;
+    auto add_problem = [&](EngLaunchPlan& pl, const OpRec& o) {
       const NodeFactor& f = c->fac[o.node];
       const DevTrain &a = tr[o.in1], &b = tr[o.in2], &out = tr[o.out];
-      EngLaunchPlan& pl = small_problem((int64_t)a.cap * b.cap, out.ny, q) ? pls : plb;
       EngProb P{};
       P.A1 = a.cores; P.bond1 = a.bonds; P.stride1 = a.stride; P.ny1 = a.ny;
       P.A2 = b.cores; P.bond2 = b.bonds; P.stride2 = b.stride; P.ny2 = b.ny;
@@ -735,11 +747,49 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
       pl.cost.push_back(B * B * B * out.ny);
       pl.cap1 = std::max(pl.cap1, a.cap); pl.cap2 = std::max(pl.cap2, b.cap);
       pl.ny1 = std::max(pl.ny1, a.ny); pl.ny2 = std::max(pl.ny2, b.ny); pl.ny = std::max(pl.ny, out.ny);
+    };
+    auto small_level = [&](int lev) -> int {
+      EngLaunchPlan pls; pls.q = q; pls.capout = cap; pls.small = true;
+      for (const OpRec& o : ops) if (o.level == lev && is_small(o)) { add_problem(pls, o); avail[o.out] = 1; }
+      return launch_engine(c, pls, trunc, false, &ms_orth, &n_orth);
+    };
+    if (pack_ok) {
+      int rc = small_level(1);
+      if (rc != MPBP_OK) return rc;
+      std::vector<int> rem;                       // indices into ops of the 512-thread problems not launched yet
+      for (int k = 0; k < (int)ops.size(); k++) if (!is_small(ops[k])) rem.push_back(k);
+      std::vector<char> needed(specs.size(), 0);  // trains some remaining 512-thread problem reads
+      const int round = std::max(1, c->num_cu);
+      while (!rem.empty()) {
+        std::vector<int> ready, later;
+        for (int k : rem) (avail[ops[k].in1] && avail[ops[k].in2] ? ready : later).push_back(k);
+        if (ready.empty()) return c->fail(MPBP_EINVAL, "internal: cavity dependency graph is not acyclic");
+        if ((int)ready.size() > round && !later.empty()) {
+          std::fill(needed.begin(), needed.end(), 0);
+          for (int k : later) { needed[ops[k].in1] = 1; needed[ops[k].in2] = 1; }
+          std::stable_sort(ready.begin(), ready.end(), [&](int a, int b) { return needed[ops[a].out] > needed[ops[b].out]; });
+          const size_t take = (ready.size() / round) * round;
+          later.insert(later.end(), ready.begin() + take, ready.end());
+          ready.resize(take);
+        }
+        EngLaunchPlan plb; plb.q = q; plb.capout = cap;
+        for (int k : ready) add_problem(plb, ops[k]);
+        rc = launch_engine(c, plb, trunc, true, &ms_orth, &n_orth);
+        if (rc != MPBP_OK) return rc;
+        for (int k : ready) avail[ops[k].out] = 1;
+        rem.swap(later);
+      }
+      for (int lev = 2; lev <= maxlevel; lev++) { rc = small_level(lev); if (rc != MPBP_OK) return rc; }
+    } else {
+      for (int lev = 1; lev <= maxlevel; lev++) {
+        EngLaunchPlan plb; plb.q = q; plb.capout = cap;
+        for (const OpRec& o : ops) if (o.level == lev && !is_small(o)) add_problem(plb, o);
+        int rc = launch_engine(c, plb, trunc, true, &ms_orth, &n_orth);
+        if (rc != MPBP_OK) return rc;
+        rc = small_level(lev);
+        if (rc != MPBP_OK) return rc;
+      }
     }
-    int rc = launch_engine(c, plb, trunc, true, &ms_orth, &n_orth);
-    if (rc != MPBP_OK) return rc;
-    rc = launch_engine(c, pls, trunc, false, &ms_orth, &n_orth);
-    if (rc != MPBP_OK) return rc;
   }
   // ---------------------------------------------------------------- finalise messages + beliefs
   {
