@@ -530,6 +530,10 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return pl.cost[a] > pl.cost[b]; });
   std::vector<EngProb> sorted(nprob);
   for (int i = 0; i < nprob; i++) sorted[i] = pl.probs[idx[i]];
+  // few single-wave problems (at most two rounds of 512-thread workgroups): the 512-thread engine finishes them
+  // sooner, a single wave per problem only pays off when there are enough problems to fill 4 of them per CU
+  // (MPBP_DEBUG_FORCE_SMALL=1 keeps them on the single-wave engine so that small tests cover it)
+  if (pl.small && nprob <= 2 * c->num_cu && !getenv("MPBP_DEBUG_FORCE_SMALL")) pl.small = false;
   EngCfg cfg; size_t lds_bytes;
   plan_cfg(pl, c->L, trunc, cfg, lds_bytes);
   // phase timers cover the 512-thread cavity launches; MPBP_PROF_SMALL=1 covers the single-wave launches instead

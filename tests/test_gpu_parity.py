@@ -362,6 +362,25 @@ def test_large_problem_code_paths_forced(monkeypatch):
     assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
 
 
+def test_single_wave_engine_variant_forced(monkeypatch):
+    """Small problems run on single-wave workgroups (v64::eng_kernel) only when there are many of them; with few
+    (every small test) the launcher prefers the 512-thread engine.  MPBP_DEBUG_FORCE_SMALL=1 keeps them on the
+    single-wave engine: finalisation, bond-1 products and - with max_bond 4 - the cavity products themselves."""
+    monkeypatch.setenv("MPBP_DEBUG_FORCE_SMALL", "1")
+    for Mb in (4, 8):
+        N, T = 8, 6
+        lam, rho, gam = 0.2, 0.1, 0.15
+        A, phi = _loopy(N, T, lam, rho, gam)
+        bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+        obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+        for s in range(2):
+            M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+            O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
+            assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"max_bond {Mb} sweep {s}"
+        assert abs(M.bethe_free_energy(bp) - O.bethe_free_energy(obp)) < RTOL * max(1.0, abs(O.bethe_free_energy(obp)))
+        assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
+
+
 def test_autocorrelations_match_enumeration():
     """reference test/sis_small_tree.jl:36-49: two-time observables from the belief trains (`bp.b[i]`)."""
     from oracle.exact import exact_autocorrelations
