@@ -139,7 +139,7 @@ def main():
     phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
     bp = M.mpbp(g, [[w] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb, device=local, slot_of_edge=slot,
                 n_slots=world * S, ext_cores=cores_t.data_ptr(), ext_bonds=bonds_t.data_ptr())
-    bp._L.mpbp_set_profiling(bp._h, 1)
+    bp._L.mpbp_set_profiling(bp._h, 2 if args.phase_profile else 1)
     lo, hi = shards[rank]
     owned = np.arange(lo, hi, dtype=np.int32)
     trunc = M.TruncBond(Mb)

@@ -172,7 +172,8 @@ int mpbp_free_energy(mpbp_ctx* ctx, double* f_node /* [n_nodes] */);
 /* log z_i and sum_j log z_{i->j} of the last update of every node (diagnostics / parity tests) */
 int mpbp_logz(mpbp_ctx* ctx, double* logz_node /* [n_nodes] */, double* logz_msg /* [n_edges] */);
 
-/* Enable/disable per-kernel HIP-event timing of the dominant kernel family (costs a sync per launch). */
+/* on = 1: per-launch HIP-event timing of the dominant kernel family (mpbp_stats.ms_orth; costs a sync per launch);
+ * on = 2: additionally the in-kernel phase timers read by mpbp_phase_profile; 0: off. */
 int mpbp_set_profiling(mpbp_ctx* ctx, int32_t on);
 /* Workgroup-seconds spent per engine phase since the last reset (profiling on), summed over workgroups;
  * phases in the order of wg::PH_* (csrc/wg_blocks.h). */

@@ -84,7 +84,7 @@ struct mpbp_ctx {
   std::vector<int64_t> pyy_base;   // per node: offset of prob_yy blob
   Arena arena, scratch;
   int num_cu = 256;
-  bool profiling = false;
+  int profiling = 0;            // 0 off, 1 HIP-event timing of the cavity launches, 2 also the in-kernel phase timers
   std::string err;
   mpbp_stats last{};
 
@@ -209,7 +209,7 @@ extern "C" int mpbp_slab_pointers(const mpbp_ctx* c, void** cores, void** bonds)
   if (bonds) *bonds = c->d_bonds;
   return MPBP_OK;
 }
-extern "C" int mpbp_set_profiling(mpbp_ctx* c, int32_t on) { if (!c) return MPBP_EINVAL; c->profiling = on != 0; return MPBP_OK; }
+extern "C" int mpbp_set_profiling(mpbp_ctx* c, int32_t on) { if (!c) return MPBP_EINVAL; c->profiling = on < 0 ? 0 : on; return MPBP_OK; }
 extern "C" int mpbp_phase_profile(mpbp_ctx* c, double* seconds, int32_t n, int32_t reset) {
   if (!c || !seconds) return MPBP_EINVAL;
   hipSetDevice(c->device);
@@ -538,7 +538,7 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   plan_cfg(pl, c->L, trunc, cfg, lds_bytes);
   // phase timers cover the 512-thread cavity launches; MPBP_PROF_SMALL=1 covers the single-wave launches instead
   static const bool prof_small = [] { const char* e = getenv("MPBP_PROF_SMALL"); return e && e[0] == '1'; }();
-  cfg.prof = (c->profiling && (prof_small ? pl.small : count_as_orth)) ? c->d_prof : nullptr;
+  cfg.prof = (c->profiling >= 2 && (prof_small ? pl.small : count_as_orth)) ? c->d_prof : nullptr;
   const void* kern = pl.small ? (const void*)v64::eng_kernel : (const void*)v512::eng_kernel;
   const int nthreads = pl.small ? 64 : 512;
   HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
