@@ -9,4 +9,6 @@ from .models import SIS, Glauber, Ising
 from .mpbp import (CB_BP, MPBP, autocorrelations, autocovariances, belief_train, twovar_marginals, IndexedBiDiGraph, InfiniteBipartiteRegularGraph, InfiniteRegularGraph, TruncBond,
                    TruncBondMax, TruncBondThresh, TruncThresh, beliefs, bethe_free_energy, color_classes,
                    default_truncator, iterate, means, mpbp, mpbp_infinite_bipartite_graph, mpbp_infinite_graph,
-                   onebpiter, pair_beliefs, reset_messages)
+                   onebpiter, pair_beliefs, reset_messages, pair_beliefs_as_mpem, pair_correlations,
+                   alternate_marginals, alternate_correlations, expectation, logprob, reset, reset_observations,
+                   is_free_dynamics)

@@ -71,6 +71,25 @@ class RecursiveBPFactor:
         """Hashable identity used to evaluate the tables once per distinct (factor, degree)."""
         return (type(self).__name__, id(self))
 
+    def __call__(self, xnext, xnbrs, xi):
+        """`w(x_i^{t+1}, x_∂i^t, x_i^t)`: the transition probability, by folding the neighbours one at a time
+        through `prob_xy` / `prob_yy` and closing with `prob_y` - the recursion that defines a RecursiveBPFactor
+        (src/recursive_bp_factor.jl:29-47, `RecursiveTraceFactor`).  States are 1-based."""
+        d = len(xnbrs)
+        py = np.array([self.prob_y0(y, xi) for y in range(1, self.nstates(0) + 1)])
+        for k, xk in enumerate(xnbrs):
+            pk = np.array([self.prob_xy(y, xk, xi, k + 1) for y in range(1, self.nstates(1) + 1)])
+            ny = self.nstates(k + 1)
+            new = np.zeros(ny)
+            for y in range(ny):
+                for y1 in range(len(py)):
+                    if py[y1] == 0.0:
+                        continue
+                    for y2 in range(len(pk)):
+                        new[y] += self.prob_yy(y + 1, y1 + 1, y2 + 1, xi, k, 1) * py[y1] * pk[y2]
+            py = new
+        return float(sum(self.prob_y(xnext, xi, y + 1, d) * py[y] for y in range(len(py))))
+
 
 class SISFactor(RecursiveBPFactor):
     """src/Models/epidemics/sis_bp.jl:4-15,18,61-78"""

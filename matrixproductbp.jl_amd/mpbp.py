@@ -18,7 +18,9 @@ from .factors import RecursiveBPFactor
 
 __all__ = ["IndexedBiDiGraph", "InfiniteRegularGraph", "InfiniteBipartiteRegularGraph", "MPBP", "mpbp",
            "mpbp_infinite_graph", "mpbp_infinite_bipartite_graph", "iterate", "onebpiter", "CB_BP", "beliefs",
-           "means", "belief_train", "twovar_marginals", "autocorrelations", "autocovariances", "pair_beliefs", "bethe_free_energy", "reset_messages", "TruncThresh", "TruncBond",
+           "means", "belief_train", "twovar_marginals", "autocorrelations", "autocovariances", "pair_beliefs",
+           "pair_beliefs_as_mpem", "pair_correlations", "alternate_marginals", "alternate_correlations", "expectation",
+           "logprob", "reset", "reset_observations", "is_free_dynamics", "bethe_free_energy", "reset_messages", "TruncThresh", "TruncBond",
            "TruncBondMax", "TruncBondThresh", "default_truncator", "color_classes"]
 
 
@@ -488,6 +490,114 @@ def pair_beliefs(bp: MPBP):
             for k in range(g.colptr[j], g.colptr[j + 1]):
                 logz[j] += (1 / dj - 0.5) * lz[k]
     return b, logz
+
+
+def _rev_edge(g, e):
+    if isinstance(g, InfiniteRegularGraph):
+        return 0
+    if isinstance(g, InfiniteBipartiteRegularGraph):
+        return 1 - e
+    return int(g.rev[e])
+
+
+def expectation(f, p):
+    """`expectation(f, p)` of the reference for a vector or a matrix of probabilities (1-based states)."""
+    p = np.asarray(p)
+    if p.ndim == 1:
+        return float(sum(f(x + 1) * p[x] for x in range(p.shape[0])))
+    return float(sum(f(x + 1, y + 1) * p[x, y] for x in range(p.shape[0]) for y in range(p.shape[1])))
+
+
+def pair_beliefs_as_mpem(bp: MPBP, edges=None):
+    """src/mpbp.jl:208-216, src/bp_core.jl:95-101: for the directed edge e = (i -> j) the (unnormalised) train
+    `C[t][(a,b),(a',b'),x_i,x_j] = mu_ij[t][a,a',x_i,x_j] mu_ji[t][b,b',x_j,x_i] psi_ij[t][x_i,x_j]`, built on the
+    host from the downloaded messages.  Returns a dict edge -> list of cores (bond = product of the two bonds)."""
+    g, q, T = bp.g, bp.q, bp.T
+    sel = list(range(g.ne())) if edges is None else [int(e) for e in edges]
+    msgs = bp.get_messages(edges=sorted(set(sel) | {_rev_edge(g, e) for e in sel}))
+    out = {}
+    for e in sel:
+        A, B = msgs[e], msgs[_rev_edge(g, e)]
+        cores = []
+        for t in range(T + 1):
+            a, b = A[t], B[t]
+            c = np.einsum("acxy,bdyx,xy->abcdxy", a, b, bp.psi[:, :, t, e])
+            cores.append(c.reshape(a.shape[0] * b.shape[0], a.shape[1] * b.shape[1], q, q))
+        out[e] = cores
+    return out
+
+
+def pair_correlations(f, bp: MPBP):
+    """src/mpbp.jl:264-267: `<f(x_i^t, x_j^t)>` per directed edge."""
+    return [[expectation(f, bt) for bt in be] for be in pair_beliefs(bp)[0]]
+
+
+def alternate_marginals(bp: MPBP, edges=None):
+    """src/mpbp.jl:270-280: `p(x_i^t, x_j^{t+1})`, t = 0..T-1, per directed edge (i -> j): the (t, t+1) two-time
+    marginal of the pair belief train, summed over x_j^t and x_i^{t+1}.  Returns a dict edge -> list over t."""
+    out = {}
+    for e, cores in pair_beliefs_as_mpem(bp, edges).items():
+        L = len(cores)
+        summed = [c.sum(axis=(2, 3)) for c in cores]
+        r = [None] * (L + 1)
+        r[L] = np.ones(1)
+        for t in range(L - 1, -1, -1):
+            v = summed[t] @ r[t + 1]
+            r[t] = v / np.abs(v).max()
+        lv = np.ones(1)
+        res = []
+        for t in range(L - 1):
+            left = np.einsum("m,mnx->xn", lv, cores[t].sum(axis=3))          # keep x_i^t
+            right = np.einsum("mny,n->my", cores[t + 1].sum(axis=2), r[t + 2])   # keep x_j^{t+1}
+            p = left @ right
+            res.append(p / p.sum())
+            lv = lv @ summed[t]
+            lv = lv / np.abs(lv).max()
+        out[e] = res
+    return out
+
+
+def alternate_correlations(f, bp: MPBP, edges=None):
+    """src/mpbp.jl:283-286"""
+    return {e: [expectation(f, p) for p in am] for e, am in alternate_marginals(bp, edges).items()}
+
+
+def logprob(bp: MPBP, x):
+    """src/mpbp.jl:301-324: log of the (unnormalised) posterior weight of the trajectory `x[i, t]` (1-based)."""
+    g, T = bp.g, bp.T
+    N = g.nv()
+    x = np.asarray(x)
+    assert x.shape == (N, T + 1)
+    with np.errstate(divide="ignore"):
+        lp = sum(np.log(bp.phi[x[i, 0] - 1, 0, i]) for i in range(N))
+        for t in range(T):
+            for i in range(N):
+                nb = [int(v) for v in g.neighbors(i)]
+                lp += np.log(bp.w[i][t](int(x[i, t + 1]), [int(x[j, t]) for j in nb], int(x[i, t])))
+                lp += np.log(bp.phi[x[i, t + 1] - 1, t + 1, i])
+        for t in range(T + 1):
+            for (i, j, e) in g.edges():
+                lp += 0.5 * np.log(bp.psi[x[i, t] - 1, x[j, t] - 1, t, e])
+    return float(lp)
+
+
+def reset_observations(bp: MPBP):
+    """src/mpbp.jl:89-95: all `phi` := 1."""
+    bp.phi[:] = 1.0
+    _lib.check(bp._L.mpbp_set_phi(bp._h, _dp(np.asfortranarray(bp.phi).ravel(order="F"))), bp._h)
+
+
+def reset(bp: MPBP, messages=True, beliefs=True, observations=False):
+    """src/mpbp.jl:97-102 (the beliefs live on the device and are overwritten by the next update)."""
+    if messages:
+        reset_messages(bp)
+    if observations:
+        reset_observations(bp)
+
+
+def is_free_dynamics(bp: MPBP):
+    """src/mpbp.jl:105-111: no reweighting <-> every phi but the one at time zero is constant in x."""
+    return bool(np.all(bp.phi[:, 1:, :] == bp.phi[:1, 1:, :]))
 
 
 def bethe_free_energy(bp: MPBP):

@@ -399,3 +399,85 @@ def test_autocorrelations_match_enumeration():
     # the belief train is normalised and reproduces the marginals
     tr = M.belief_train(bp, 0)
     assert tr[0].shape[0] == 1 and tr[-1].shape[1] == 1
+
+
+@pytest.mark.parametrize("case", ["path3_plus_isolated_T1", "path3_plus_isolated_T5", "single_edge", "hub6"])
+def test_edge_case_graphs(case):
+    """Ragged inputs: an isolated node (degree 0: no cavity at all), leaves, the shortest possible chain (T = 1),
+    a two-node graph, and a degree-6 hub (cavity chain of depth 6, packed launches)."""
+    if case.startswith("path3"):
+        A = np.zeros((4, 4)); A[0, 1] = A[1, 0] = A[1, 2] = A[2, 1] = 1
+        T, Mb = (1 if case.endswith("T1") else 5), 4
+    elif case == "single_edge":
+        A = np.zeros((2, 2)); A[0, 1] = A[1, 0] = 1
+        T, Mb = 3, 4
+    else:
+        A = np.zeros((7, 7)); A[0, 1:] = 1; A[1:, 0] = 1
+        T, Mb = 4, 6
+    N = A.shape[0]
+    lam, rho, gam = 0.3, 0.2, 0.2
+    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    for s in range(2):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
+    assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL
+    assert abs(M.bethe_free_energy(bp) - O.bethe_free_energy(obp)) < RTOL * max(1.0, abs(O.bethe_free_energy(obp)))
+
+
+def test_more_observables_match_enumeration_and_oracle():
+    """pair_correlations, alternate_marginals / alternate_correlations (src/mpbp.jl:264-286), logprob
+    (src/mpbp.jl:301-324), the factor call `w(x', x_nbrs, x)`, reset_observations / is_free_dynamics
+    (src/mpbp.jl:89-111) on the reference's 4-star (test/sis_small_tree.jl)."""
+    A, lam, rho, alpha, phi, T = _sis_star_inputs()
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, 2, T, phi=phi, max_bond=16)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBondMax(4), schedule="colored")
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, [2] * 4, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    # p(x_i^t, x_j^{t+1}) per directed edge from the enumeration
+    am = M.alternate_marginals(bp)
+    for (i, j, e) in obp.g.edges():
+        for t in range(T):
+            a, b = i * (T + 1) + t, j * (T + 1) + t + 1
+            m = p.sum(axis=tuple(c for c in range(p.ndim) if c not in (a, b)))
+            m = m if a < b else m.T
+            assert np.abs(am[e][t] - m).max() < 1e-9, (e, t)
+    f2 = lambda x, y: (x - 1) * (y - 1)
+    ac = M.alternate_correlations(f2, bp)
+    assert abs(ac[0][0] - sum(f2(x + 1, y + 1) * am[0][0][x, y] for x in range(2) for y in range(2))) < 1e-14
+    pc = M.pair_correlations(f2, bp)
+    pb = M.pair_beliefs(bp)[0]
+    assert abs(pc[2][1] - pb[2][1][1, 1]) < 1e-14
+    # the train form of the pair beliefs reproduces the pair beliefs
+    tr = M.pair_beliefs_as_mpem(bp, edges=[0])[0]
+    summed = [c.sum(axis=(2, 3)) for c in tr]
+    lv, rv = [np.ones(1)], [np.ones(1)]
+    for c in summed:
+        lv.append(lv[-1] @ c)
+    for c in reversed(summed):
+        rv.append(c @ rv[-1])
+    rv = rv[::-1]
+    for t in range(T + 1):
+        m = np.einsum("m,mnxy,n->xy", lv[t], tr[t], rv[t + 1])
+        assert np.abs(m / m.sum() - pb[0][t]).max() < 1e-12
+    # logprob of a trajectory vs the oracle (and, observing nothing, the factor call sums to one)
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        X = rng.integers(0, 2, size=(4, T + 1))
+        with np.errstate(divide="ignore"):
+            a, b = M.logprob(bp, X + 1), O.logprob(obp, X)
+        assert (a == b) or abs(a - b) < 1e-12 * max(1.0, abs(b))
+    w = M.SISFactor(lam, rho, alpha)
+    for xn in ([1, 1, 2], [2, 2, 2], []):
+        for x in (1, 2):
+            assert abs(sum(w(xp, xn, x) for xp in (1, 2)) - 1.0) < 1e-14
+            assert abs(w(2, xn, x) - OF.SISFactor(lam, rho, alpha)(2, xn, x)) < 1e-15
+    assert not M.is_free_dynamics(bp)          # the last time is observed
+    M.reset_observations(bp)
+    assert M.is_free_dynamics(bp)
+    M.reset(bp)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBondMax(4), schedule="colored")
+    b = M.beliefs(bp)
+    assert abs(b[0][0][1] - 0.5) < 1e-9        # free dynamics: the time-0 marginal is uniform after reset_observations
