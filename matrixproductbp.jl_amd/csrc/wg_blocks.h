@@ -548,6 +548,80 @@ __device__ __forceinline__ void qr_gram(const gdbl* Y, long ld, int rows32, int 
   }
 }
 
+// NP Gram blocks of panel x against panels y_0 .. y_{NP-1} in ONE pass over the rows (x is read once instead of
+// NP times): G_k[i + 16 j] = sum_r Vx[r][i] Vy_k[r][j], rows from `jrow` (a multiple of 16; x is zero above).
+// Results in big[256 k ...]; partials use WG_WAVES * 256 * NP doubles of `big`.  All panels full (16 reflectors).
+template <int NP>
+__device__ __forceinline__ void qr_gramN(const gdbl* Y, long ld, int rows32, int jrow, int jx, const int (&jy)[NP],
+                                         ldbl* big) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nrb = (rows32 - jrow) >> 4;
+  const gdbl* xcol = Y + (long)(jx + l15) * ld + jrow + 4 * g;
+  const gdbl* ycol[NP];
+  d4 acc[NP];
+#pragma unroll
+  for (int k = 0; k < NP; k++) { ycol[k] = Y + (long)(jy[k] + l15) * ld + jrow + 4 * g; acc[k] = d4{0, 0, 0, 0}; }
+  auto head = [&](d4& v, int rb, int jv) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rr = jrow + 16 * rb + 4 * g + e - jv;       // relative to the panel's diagonal block
+      double a = v[e];
+      a = (rr < 16) ? ((rr > l15) ? a : ((rr == l15) ? 1.0 : 0.0)) : a;
+      v[e] = (rr >= 0 && rb < nrb) ? a : 0.0;
+    }
+  };
+  d4 vx[2], vy[2][NP];
+  auto load = [&](int rb, d4& a, d4 (&b)[NP]) {
+    const int rbc = min(rb, nrb - 1);
+    a = *reinterpret_cast<const gd4*>(xcol + 16 * rbc);
+#pragma unroll
+    for (int k = 0; k < NP; k++) b[k] = *reinterpret_cast<const gd4*>(ycol[k] + 16 * rbc);
+  };
+  auto comp = [&](int rb, d4& a, d4 (&b)[NP]) {
+    head(a, rb, jx);
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      head(b[k], rb, jy[k]);
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[k] = mfma(a[e], b[k][e], acc[k]);
+    }
+  };
+  if (wave < nrb) load(wave, vx[0], vy[0]);
+  for (int rb = wave; rb < nrb; rb += 2 * WG_WAVES) {
+    load(rb + WG_WAVES, vx[1], vy[1]);
+    comp(rb, vx[0], vy[0]);
+    load(rb + 2 * WG_WAVES, vx[0], vy[0]);
+    comp(rb + WG_WAVES, vx[1], vy[1]);
+  }
+  constexpr int NVAL = 256 * NP;
+#pragma unroll
+  for (int k = 0; k < NP; k++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) big[wave * NVAL + 256 * k + (g + 4 * r) + 16 * l15] = acc[k][r];
+  __syncthreads();
+  if (WG_WAVES > 1) {
+    constexpr int PER = (NVAL + WG_THREADS - 1) / WG_THREADS;
+    double s1[PER];
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      const int idx = tid + e * WG_THREADS;
+      s1[e] = 0.0;
+      if (idx < NVAL) {
+#pragma unroll
+        for (int w2 = 0; w2 < WG_WAVES; w2++) s1[e] += big[w2 * NVAL + idx];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      const int idx = tid + e * WG_THREADS;
+      if (idx < NVAL) big[idx] = s1[e];
+    }
+    __syncthreads();
+  }
+}
+
 // T of the block reflector (dlarft) from the Gram matrix G = V^T V in `big`: row i of T depends only on its own
 // earlier entries, so lane i builds row i in registers with no synchronisation:
 //   T(i,j) = -tau_j sum_{i2=i}^{j-1} T(i,i2) G(i2,j)  (i < j),  T(j,j) = tau_j.
@@ -919,9 +993,11 @@ __device__ __forceinline__ void qr_tile_update_all(gdbl* Y, long ld, int rows32,
   __syncthreads();
 }
 
-// Update ONE 16-column tile (first column cb0) by the panel PAIR a (j0), b (j0+16) with all waves working on
-// different rows (the row-parallel counterpart of qr_trail2<1>): partial Va^T C, Vb^T C -> LDS, then every wave
-// forms Wa, Wb and applies them to its own 32-row stages.  `big`: WG_WAVES*512 doubles.
+// Update NT adjacent 16-column tiles (first column cb0) by the panel PAIR a (j0), b (j0+16) with all waves working
+// on different rows (the row-parallel counterpart of qr_trail2): partial Va^T C, Vb^T C -> LDS, then every wave
+// forms Wa, Wb and applies them to its own 32-row stages.  The V fragments are loaded once for all NT tiles.
+// `big`: WG_WAVES * 512 * NT doubles.
+template <int NT>
 __device__ __forceinline__ void qr_tile_update2_all(gdbl* Y, long ld, int rows32, int j0, int cb0, const ldbl* TsA,
                                                     const ldbl* TsB, const ldbl* Sm, ldbl* big) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -929,12 +1005,15 @@ __device__ __forceinline__ void qr_tile_update2_all(gdbl* Y, long ld, int rows32
   const int nrb = (rows32 - j0) >> 4;
   const gdbl* vacol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
   const gdbl* vbcol = Y + (long)(j0 + 16 + l15) * ld + j0 + 4 * g;
-  const gdbl* ccol = Y + (long)(cb0 + l15) * ld + j0 + 4 * g;
-  d4 acca = d4{0, 0, 0, 0}, accb = d4{0, 0, 0, 0};
+  d4 acca[NT], accb[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) { acca[q] = d4{0, 0, 0, 0}; accb[q] = d4{0, 0, 0, 0}; }
   for (int rb = wave; rb < nrb; rb += WG_WAVES) {
     d4 va = *reinterpret_cast<const gd4*>(vacol + 16 * rb);
     d4 vb = *reinterpret_cast<const gd4*>(vbcol + 16 * rb);
-    d4 c = *reinterpret_cast<const gd4*>(ccol + 16 * rb);
+    d4 c[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const gd4*>(Y + (long)(cb0 + 16 * q + l15) * ld + j0 + 4 * g + 16 * rb);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int rho = 4 * g + e;
@@ -945,35 +1024,44 @@ __device__ __forceinline__ void qr_tile_update2_all(gdbl* Y, long ld, int rows32
       vb[e] = (rb >= 1) ? b : 0.0;
     }
 #pragma unroll
-    for (int e = 0; e < 4; e++) { acca = mfma(va[e], c[e], acca); accb = mfma(vb[e], c[e], accb); }
-  }
+    for (int e = 0; e < 4; e++)
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    big[wave * 512 + (g + 4 * r) + 16 * l15] = acca[r];
-    big[wave * 512 + 256 + (g + 4 * r) + 16 * l15] = accb[r];
+      for (int q = 0; q < NT; q++) { acca[q] = mfma(va[e], c[q][e], acca[q]); accb[q] = mfma(vb[e], c[q][e], accb[q]); }
   }
-  __syncthreads();
-  d4 wa0 = d4{0, 0, 0, 0}, wb0 = d4{0, 0, 0, 0};
+  constexpr int NVAL = 512 * NT;
 #pragma unroll
-  for (int w = 0; w < WG_WAVES; w++)
+  for (int q = 0; q < NT; q++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      wa0[r] += big[w * 512 + (g + 4 * r) + 16 * l15];
-      wb0[r] += big[w * 512 + 256 + (g + 4 * r) + 16 * l15];
+      big[wave * NVAL + 512 * q + (g + 4 * r) + 16 * l15] = acca[q][r];
+      big[wave * NVAL + 512 * q + 256 + (g + 4 * r) + 16 * l15] = accb[q][r];
     }
-  d4 wa = d4{0, 0, 0, 0}, wb = d4{0, 0, 0, 0};
+  __syncthreads();
+  d4 wa[NT], wb[NT];
 #pragma unroll
-  for (int s = 0; s < 4; s++) wa = mfma(TsA[(4 * s + g) + 16 * l15], wa0[s], wa);
-  d4 t = wb0;
+  for (int q = 0; q < NT; q++) {
+    d4 wa0 = d4{0, 0, 0, 0}, wb0 = d4{0, 0, 0, 0};
 #pragma unroll
-  for (int s = 0; s < 4; s++) t = mfma(-Sm[l15 + 16 * (4 * s + g)], wa[s], t);
+    for (int w = 0; w < WG_WAVES; w++)
 #pragma unroll
-  for (int s = 0; s < 4; s++) wb = mfma(TsB[(4 * s + g) + 16 * l15], t[s], wb);
+      for (int r = 0; r < 4; r++) {
+        wa0[r] += big[w * NVAL + 512 * q + (g + 4 * r) + 16 * l15];
+        wb0[r] += big[w * NVAL + 512 * q + 256 + (g + 4 * r) + 16 * l15];
+      }
+    wa[q] = d4{0, 0, 0, 0}; wb[q] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) wa[q] = mfma(TsA[(4 * s + g) + 16 * l15], wa0[s], wa[q]);
+    d4 t = wb0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) t = mfma(-Sm[l15 + 16 * (4 * s + g)], wa[q][s], t);
+#pragma unroll
+    for (int s = 0; s < 4; s++) wb[q] = mfma(TsB[(4 * s + g) + 16 * l15], t[s], wb[q]);
+  }
   const int jb = j0 & ~31;
   const int nst = (rows32 - jb) >> 5;
   for (int st = wave; st < nst; st += WG_WAVES) {
     const int row = jb + 32 * st + 2 * l15;
-    d2 va[4], vb[4], c[4];
+    d2 va[4], vb[4];
 #pragma unroll
     for (int s2 = 0; s2 < 4; s2++) {
       const int k = 4 * s2 + g;
@@ -991,17 +1079,21 @@ __device__ __forceinline__ void qr_tile_update2_all(gdbl* Y, long ld, int rows32
       va[s2] = xa; vb[s2] = xb;
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row);
+    for (int q = 0; q < NT; q++) {
+      d2 c[4];
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-      d4 acc = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
+      for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
 #pragma unroll
-      for (int s2 = 0; s2 < 4; s2++) { acc = mfma(-wa[s2], va[s2][e], acc); acc = mfma(-wb[s2], vb[s2][e], acc); }
+      for (int e = 0; e < 2; e++) {
+        d4 acc = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
 #pragma unroll
-      for (int r = 0; r < 4; r++) c[r][e] = acc[r];
+        for (int s2 = 0; s2 < 4; s2++) { acc = mfma(-wa[q][s2], va[s2][e], acc); acc = mfma(-wb[q][s2], vb[s2][e], acc); }
+#pragma unroll
+        for (int r = 0; r < 4; r++) c[r][e] = acc[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) *reinterpret_cast<gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[r];
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) *reinterpret_cast<gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row) = c[r];
   }
   __syncthreads();
 }
@@ -1128,7 +1220,7 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
   }
 }
 
-// `big`: >= WG_WAVES*512 doubles of LDS scratch (may alias the gemm tile buffers)
+// `big`: >= WG_WAVES*1024 doubles of LDS scratch when QR_QUAD (else WG_WAVES*512); may alias the gemm tile buffers
 __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1180,6 +1272,25 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
     qr_T_from_gram(big, tau2, 16, T2);
     if (pr) prof_mark(pr, *plast, fine ? 16 : ph_panel);
   };
+  // second pair (c, d) of a quad whose first pair sits at ja: as factor_pair, with the cross Grams against the
+  // first pair taken in the same pass over the rows as each panel's own Gram
+  auto factor_pair2 = [&](int ja) {
+    const int jc = ja + 32, jd = ja + 48;
+    factor_panel(jc, 16, TsC, tauC);
+    { const int jy[3] = {jc, ja, ja + 16}; qr_gramN<3>(Y, ld, rows32, jc, jc, jy, big); }      // Gcc, Sca, Scb
+    for (int i = tid; i < 256; i += WG_THREADS) { Sca[i] = big[256 + i]; Scb[i] = big[512 + i]; }
+    if (fine) prof_mark(pr, *plast, 15);
+    qr_T_from_gram(big, tauC, 16, TsC);
+    if (pr) prof_mark(pr, *plast, fine ? 16 : ph_panel);
+    qr_tile_update_all(Y, ld, rows32, jc, 16, jd, TsC, big);
+    if (pr) prof_mark(pr, *plast, fine ? 17 : ph_trail);
+    factor_panel(jd, 16, TsD, tauD);
+    { const int jy[4] = {jd, jc, ja, ja + 16}; qr_gramN<4>(Y, ld, rows32, jd, jd, jy, big); }  // Gdd, Sdc, Sda, Sdb
+    for (int i = tid; i < 256; i += WG_THREADS) { Sdc[i] = big[256 + i]; Sda[i] = big[512 + i]; Sdb[i] = big[768 + i]; }
+    if (fine) prof_mark(pr, *plast, 15);
+    qr_T_from_gram(big, tauD, 16, TsD);
+    if (pr) prof_mark(pr, *plast, fine ? 16 : ph_panel);
+  };
   // tiles [cstart, cols) are shared out to the waves in contiguous runs
   auto wave_tiles = [&](int cstart, int& tstart, int& tcnt) {
     const int ntl = (cols - cstart + 15) / 16;   // may be 0
@@ -1196,17 +1307,9 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
     const bool pair = !quad && fast && j0 + 32 <= kmax && j0 + 32 < cols;
     if (quad) {
       factor_pair(j0, Ts, tau, TsB, tauB, Sm);
-      qr_tile_update2_all(Y, ld, rows32, j0, j0 + 32, Ts, TsB, Sm, big);
-      qr_tile_update2_all(Y, ld, rows32, j0, j0 + 48, Ts, TsB, Sm, big);
+      qr_tile_update2_all<2>(Y, ld, rows32, j0, j0 + 32, Ts, TsB, Sm, big);
       if (pr) prof_mark(pr, *plast, fine ? 17 : ph_trail);
-      factor_pair(j0 + 32, TsC, tauC, TsD, tauD, Sdc);
-      qr_gram<true>(Y, ld, rows32, j0 + 32, j0 + 32, 16, j0, 16, j0 + 16, 16, big);       // Sca, Scb
-      for (int i = tid; i < 256; i += WG_THREADS) { Sca[i] = big[i]; Scb[i] = big[256 + i]; }
-      __syncthreads();
-      qr_gram<true>(Y, ld, rows32, j0 + 48, j0 + 48, 16, j0, 16, j0 + 16, 16, big);       // Sda, Sdb
-      for (int i = tid; i < 256; i += WG_THREADS) { Sda[i] = big[i]; Sdb[i] = big[256 + i]; }
-      __syncthreads();
-      if (pr) prof_mark(pr, *plast, fine ? 15 : ph_panel);
+      factor_pair2(j0);
       const ldbl* const Tq[4] = {Ts, TsB, TsC, TsD};
       const ldbl* const Sq[6] = {Sm, Sca, Scb, Sda, Sdb, Sdc};
       int tstart, tcnt;
