@@ -37,3 +37,7 @@ out.update({"launches": 2, "bytes_per_launch_avg": (fetch + write) / 2, "fetch_b
             "note": "memory-side (L2 fabric) traffic of the two v512::eng_kernel launches of the timed sweep; Infinity-Cache hits are included in these counters"})
 json.dump(out, open("profiles/r01_pmc_eng_kernel.json", "w"), indent=1)
 print("traffic per launch (avg): %.3f TB" % (out["bytes_per_launch_avg"] / 1e12))
+# the bench line of this same call quoted the previous PMC file: make it carry this call's measurement
+b = json.load(open("profiles/r01_bench.json"))
+b["roofline"]["traffic"] = out["bytes_per_launch_avg"]
+json.dump(b, open("profiles/r01_bench.json", "w"), indent=1)
