@@ -127,7 +127,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
     // Y1: Z[(k,n2) ; (m1,y1,xi)] = sum_n1 A1[m1,n1,y1,xi] Lf[(n1,n2),k]      Z[j + r1*bn*i], j = k + r1*n2
     const int M1 = a * ny1 * q;
     const int64_t zld = (int64_t)r1 * bn;
-    gemm_direct(M1, r1 * bn, an, A1c,
+    gemm_direct<false, true>(M1, r1 * bn, an, A1c,          // Z is written once and read once, 5 MB away: nontemporal
          [=](int i) { return (i % a) + a * an * (i / a); }, [=](int kk) { return a * kk; },
          Lf1, [=](int kk) { return (int64_t)r1 * kk; },
          [=](int j) { return (int64_t)(j % r1) + (int64_t)r1 * an * (j / r1); },
@@ -146,7 +146,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
       Y[(int64_t)ldY * Bm + idx] = 0.0;
     const int M2 = b * ny, K2 = bn * ny1;
     for (int xi = 0; xi < q; xi++) {
-      gemm_direct(M2, r1 * a, K2, E + (int64_t)xi * M2 * K2,
+      gemm_direct<true, true>(M2, r1 * a, K2, E + (int64_t)xi * M2 * K2,
            [=](int i) { return i; }, [=](int kk) { return M2 * kk; },
            Z + zld * a * ny1 * xi,
            [=](int kk) { return (int64_t)r1 * (kk % bn) + zld * a * (kk / bn); },

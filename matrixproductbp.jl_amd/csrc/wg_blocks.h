@@ -26,7 +26,8 @@ constexpr int GM_LDA = 112;  // LDS leading dims: == 16 (mod 32) doubles so that
 constexpr int GM_LDB = 144;  // ds_read_b64 half-wave land on disjoint banks
 constexpr int GM_LDS_DOUBLES = GM_KC * (GM_LDA + GM_LDB);   // 4096 doubles = 32 KiB
 
-template <class SP, class XP, class OP, class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
+template <bool NTX = false, bool NTO = false, class SP, class XP, class OP, class SRO, class SCO, class XRO, class XCO,
+          class ORO, class OCO>
 __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp, SRO sro, SCO sco,
                                                      XP Xp, XRO xro, XCO xco, OP Op, ORO oro, OCO oco,
                                                      bool accumulate);
@@ -41,7 +42,7 @@ __device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* 
 #if WG_THREADS != 512
   // the LDS staging maps below are laid out for 512 threads; smaller workgroups take the barrier-free form
   (void)xkfast; (void)lds;
-  gemm_direct(M, N, K, Sp, sro, sco, Xp, xro, xco, Op, oro, oco, accumulate);
+  gemm_direct<false, false>(M, N, K, Sp, sro, sco, Xp, xro, xco, Op, oro, oco, accumulate);
 #else
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -160,8 +161,9 @@ __device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* 
 // fragments straight from global memory (8 B per lane per k-step, all k-steps of a tile in flight together)
 // and its A fragments from wherever S lives.  No LDS staging, no __syncthreads() inside; waves never wait for
 // each other.  Same index-map interface as gemm().  Ends with a __syncthreads().
-// SP / XP / OP are address-space typed pointers (ldbl* or gdbl*, see wg_common.h).
-template <class SP, class XP, class OP, class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
+// SP / XP / OP are address-space typed pointers (ldbl* or gdbl*, see wg_common.h).  NTX / NTO: nontemporal loads of
+// X / stores of O - for streams far larger than the caches that would only evict the operands that are reused.
+template <bool NTX, bool NTO, class SP, class XP, class OP, class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
 __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp, SRO sro, SCO sco,
                                                      XP Xp, XRO xro, XCO xco, OP Op, ORO oro, OCO oco,
                                                      bool accumulate) {
@@ -197,7 +199,7 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
           const int k = 4 * (ks0 + u) + g;
           kin[u] = (ks0 + u < nks) && k < K;
           const int kc = kin[u] ? k : 0;
-          b[u] = Xp[(long)xro(kc) + cofs];          // unconditional load (valid address), masked below
+          b[u] = NTX ? __builtin_nontemporal_load(Xp + ((long)xro(kc) + cofs)) : Xp[(long)xro(kc) + cofs];   // unconditional (valid address), masked below
           so[u] = (long)sco(kc);
         }
 #pragma unroll
@@ -224,7 +226,7 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
                 OP p = Op + (long)oro(mb + row) + oc;
                 double v = acc[t][r];
                 if (accumulate) v += *p;
-                *p = v;
+                if (NTO) __builtin_nontemporal_store(v, p); else *p = v;
               }
             }
           }
@@ -1127,7 +1129,7 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
 #pragma unroll
       for (int p = 0; p < 4; p++) v[p] = *reinterpret_cast<const gd4*>(vcol[p] + 16 * rbc);
 #pragma unroll
-      for (int q = 0; q < NT; q++) c[q] = *reinterpret_cast<const gd4*>(ccol[q] + 16 * rbc);
+      for (int q = 0; q < NT; q++) c[q] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(ccol[q] + 16 * rbc));
       const bool in = rb < nrb;
 #pragma unroll
       for (int p = 0; p < 4; p++)
@@ -1199,7 +1201,7 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
       for (int q = 0; q < NT; q++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          c[q][r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row);
+          c[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row));
 #pragma unroll
       for (int q = 0; q < NT; q++) {
 #pragma unroll
@@ -1214,7 +1216,7 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
         }
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          *reinterpret_cast<gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row) = c[q][r];
+          __builtin_nontemporal_store(c[q][r], reinterpret_cast<gd2*>(Y + (long)(cb0 + 16 * q + g + 4 * r) * ld + row));
       }
     }
   }
