@@ -439,6 +439,15 @@ namespace {
 
 struct OpRec { int in1, in2, out, d1, d2, node, level; };   // indices into the train table
 
+// a pair of HIP events that is destroyed on every exit path
+struct EventPair {
+  hipEvent_t a = nullptr, b = nullptr;
+  EventPair() { hipEventCreate(&a); hipEventCreate(&b); }
+  ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+  EventPair(const EventPair&) = delete;
+  EventPair& operator=(const EventPair&) = delete;
+};
+
 static int ensure_arena(mpbp_ctx* c, Arena& a, size_t bytes) {
   if (a.cap >= bytes) return MPBP_OK;
   if (a.base) { hipFree(a.base); a.base = nullptr; a.cap = 0; }
@@ -559,8 +568,10 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   EngProb* d_probs = (EngProb*)(c->scratch.base + (((size_t)nslots * slot_bytes + 255) & ~size_t(255)));
   HIPCHK(c, hipMemcpyAsync(d_probs, sorted.data(), sizeof(EngProb) * nprob, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (count_as_orth && c->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
+  const bool timed = count_as_orth && c->profiling;
+  EventPair lev;
+  hipEvent_t e0 = timed ? lev.a : nullptr, e1 = lev.b;
+  if (timed) hipEventRecord(e0, c->stream);
   if (pl.small) hipLaunchKernelGGL(v64::eng_kernel, dim3(nslots), dim3(64), lds_bytes, c->stream, d_probs, nprob, c->d_counter, cfg, d_scr, c->d_stats);
   else hipLaunchKernelGGL(v512::eng_kernel, dim3(nslots), dim3(512), lds_bytes, c->stream, d_probs, nprob, c->d_counter, cfg, d_scr, c->d_stats);
   (void)kern;
@@ -568,7 +579,6 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   if (e0) {
     hipEventRecord(e1, c->stream); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_orth += ms; *n_orth += 1;
-    hipEventDestroy(e0); hipEventDestroy(e1);
   }
   // the host vectors `sorted` must outlive the async copy
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -590,8 +600,8 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
     if (seen[nodes[k]]) return c->fail(MPBP_EINVAL, "node %d listed twice", nodes[k]);
     seen[nodes[k]] = 1;
   }
-  hipEvent_t ev0, ev1;
-  hipEventCreate(&ev0); hipEventCreate(&ev1);
+  EventPair evs;
+  hipEvent_t ev0 = evs.a, ev1 = evs.b;
   hipEventRecord(ev0, c->stream);
   HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(EngStats), c->stream));
   float ms_orth = 0.f; int n_orth = 0;
@@ -947,7 +957,6 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
   EngStats hs;
   HIPCHK(c, hipMemcpy(&hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost));
   float ms = 0; hipEventElapsedTime(&ms, ev0, ev1);
-  hipEventDestroy(ev0); hipEventDestroy(ev1);
   mpbp_stats st{};
   { double v; unsigned long long b = hs.maxerr_bits; memcpy(&v, &b, 8); st.maxerr = v; }
   st.n_compress = (int64_t)hs.n_compress; st.nan_flag = hs.nan_flag; st.capacity_flag = hs.capacity_flag;
