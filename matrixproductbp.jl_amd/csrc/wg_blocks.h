@@ -310,32 +310,50 @@ constexpr bool QR_QUAD = (WG_THREADS == 512);   // aggregate four panels (K = 64
 constexpr int QR_LDS_PAIR = QR_LDS_BASE + 256 + 256 + 16;
 constexpr int QR_LDS_DOUBLES = QR_LDS_PAIR + (QR_QUAD ? 7 * 256 + 32 : 0);
 
+// Cross-lane exchanges without the LDS crossbar (ds_bpermute): gfx950's v_permlane32_swap / v_permlane16_swap do a
+// whole butterfly level in one instruction per 32-bit half, DPP row_mirror / row_half_mirror / quad_perm the rest.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// lanes < 32: x(l) + x(l+32);  lanes >= 32: y(l-32) + y(l)
+__device__ __forceinline__ double swap_add32(double x, double y) {
+  const u32x2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const u32x2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// within every 32 lanes: lanes with bit 4 clear: x(l) + x(l+16);  bit 4 set: y(l-16) + y(l)
+__device__ __forceinline__ double swap_add16(double x, double y) {
+  const u32x2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const u32x2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// DPP move of a double: 0x140 row_mirror (l <-> 15-l), 0x141 row_half_mirror (l <-> 7-l), 0x4E / 0xB1 quad xor 2 / 1
+template <int CTRL>
+__device__ __forceinline__ double dpp64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 // 16 per-lane partial values -> lanes with (lane & 3) == 0 hold the wave total of value
-// idx = ((lane>>5)&1)<<3 | ((lane>>4)&1)<<2 | ((lane>>3)&1)<<1 | ((lane>>2)&1)   (17 shuffles instead of 96)
+// idx = ((lane>>5)&1)<<3 | ((lane>>4)&1)<<2 | ((lane>>3)&1)<<1 | ((lane>>2)&1).  Each level pairs the lanes whose
+// bit differs (by a mirror below 16 lanes: any pairing works, the later levels sum over all lower bits).
 __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane, int& idx) {
   double a8[8], a4[4], a2[2], a1;
   const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    double keep = b5 ? v[i + 8] : v[i], send = b5 ? v[i] : v[i + 8];
-    a8[i] = keep + __shfl_xor(send, 32, 64);
-  }
+  for (int i = 0; i < 8; i++) a8[i] = swap_add32(v[i], v[i + 8]);
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    double keep = b4 ? a8[i + 4] : a8[i], send = b4 ? a8[i] : a8[i + 4];
-    a4[i] = keep + __shfl_xor(send, 16, 64);
-  }
+  for (int i = 0; i < 4; i++) a4[i] = swap_add16(a8[i], a8[i + 4]);
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     double keep = b3 ? a4[i + 2] : a4[i], send = b3 ? a4[i] : a4[i + 2];
-    a2[i] = keep + __shfl_xor(send, 8, 64);
+    a2[i] = keep + dpp64<0x140>(send);
   }
   {
     double keep = b2 ? a2[1] : a2[0], send = b2 ? a2[0] : a2[1];
-    a1 = keep + __shfl_xor(send, 4, 64);
+    a1 = keep + dpp64<0x141>(send);
   }
-  a1 += __shfl_xor(a1, 2, 64);
-  a1 += __shfl_xor(a1, 1, 64);
+  a1 += dpp64<0x4E>(a1);
+  a1 += dpp64<0xB1>(a1);
   idx = (b5 ? 8 : 0) | (b4 ? 4 : 0) | (b3 ? 2 : 0) | (b2 ? 1 : 0);
   return a1;
 }
@@ -346,22 +364,16 @@ __device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane, int&
   double a4[4], a2[2], a1;
   const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    double keep = b5 ? v[i + 4] : v[i], send = b5 ? v[i] : v[i + 4];
-    a4[i] = keep + __shfl_xor(send, 32, 64);
-  }
+  for (int i = 0; i < 4; i++) a4[i] = swap_add32(v[i], v[i + 4]);
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
-    double keep = b4 ? a4[i + 2] : a4[i], send = b4 ? a4[i] : a4[i + 2];
-    a2[i] = keep + __shfl_xor(send, 16, 64);
-  }
+  for (int i = 0; i < 2; i++) a2[i] = swap_add16(a4[i], a4[i + 2]);
   {
     double keep = b3 ? a2[1] : a2[0], send = b3 ? a2[0] : a2[1];
-    a1 = keep + __shfl_xor(send, 8, 64);
+    a1 = keep + dpp64<0x140>(send);
   }
-  a1 += __shfl_xor(a1, 4, 64);
-  a1 += __shfl_xor(a1, 2, 64);
-  a1 += __shfl_xor(a1, 1, 64);
+  a1 += dpp64<0x141>(a1);
+  a1 += dpp64<0x4E>(a1);
+  a1 += dpp64<0xB1>(a1);
   idx = (b5 ? 4 : 0) | (b4 ? 2 : 0) | (b3 ? 1 : 0);
   return a1;
 }
@@ -421,9 +433,21 @@ __device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const b
   double beta, tj, scale;
   if (ss == 0.0) { beta = alpha; tj = 0.0; scale = 0.0; }
   else {
-    beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-    tj = (beta - alpha) / beta;
-    scale = 1.0 / (alpha - beta);
+    // dlarfg with one rsq and one rcp (hardware seeds + Newton steps) instead of a sqrt and two IEEE divisions:
+    // every thread of the workgroup evaluates this chain on the critical path of each column
+    const double n2 = alpha * alpha + ss;
+    double ri = __builtin_amdgcn_rsq(n2);
+    ri = ri * (1.5 - 0.5 * n2 * ri * ri);
+    ri = ri * (1.5 - 0.5 * n2 * ri * ri);              // 1 / ||x||
+    double nrm = n2 * ri;
+    nrm = nrm + 0.5 * ri * (n2 - nrm * nrm);           // ||x||
+    beta = -copysign(nrm, alpha);
+    tj = 1.0 + fabs(alpha) * ri;                       // (beta - alpha) / beta = 1 - alpha / beta
+    const double dd = alpha - beta;                    // same sign as alpha, |dd| = |alpha| + ||x||: no cancellation
+    double rd = __builtin_amdgcn_rcp(dd);
+    rd = rd * (2.0 - dd * rd);
+    rd = rd * (2.0 - dd * rd);
+    scale = rd;
   }
   if (tid == 0) tau[JJ] = tj;
   double tw[QR_NB];
@@ -1445,9 +1469,10 @@ __device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n,
 #pragma unroll
               for (int i = 0; i < JC; i++) { al += x[i] * x[i]; be += y[i] * y[i]; ga += x[i] * y[i]; }
             }
-            for (int o = LP >> 1; o > 0; o >>= 1) {
-              al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64);
-            }
+            // sum over the LP lanes of the pair group (LP = 1, 2, 4, 8; groups are aligned): DPP moves, no LDS crossbar
+            if (lg >= 3) { al += dpp64<0x141>(al); be += dpp64<0x141>(be); ga += dpp64<0x141>(ga); }
+            if (lg >= 2) { al += dpp64<0x4E>(al); be += dpp64<0x4E>(be); ga += dpp64<0x4E>(ga); }
+            if (lg >= 1) { al += dpp64<0xB1>(al); be += dpp64<0xB1>(be); ga += dpp64<0xB1>(ga); }
             if (ga * ga > (tol * tol) * (al * be) && al > nul && be > nul) {
               worst = fmax(worst, ga * ga / (al * be));
               // t = tan(theta) = sgn(d) 2 ga / (|d| + sqrt(d^2 + 4 ga^2)), d = be - al  (smaller root);
