@@ -305,7 +305,7 @@ __device__ inline double wg_maxabs(AP A, long ld, int rows, int cols, ldbl* red)
 constexpr int QR_NB = 16;
 constexpr int QR_RS = 4;      // rows per thread of the register panel
 constexpr int QR_TC = 3;      // column tiles a wave updates together
-constexpr int QR_LDS_BASE = WG_WAVES * 16 + 16 * 16 + 16 + 2 * 32 + 2 * 16;
+constexpr int QR_LDS_BASE = 2 * WG_WAVES * 16 + 16 * 16 + 16 + 2 * 32 + 2 * 16;   // [red x2][Ts][tau][bc]
 constexpr bool QR_QUAD = (WG_THREADS == 512);   // aggregate four panels (K = 64 trailing updates) - 512-thread variant only
 constexpr int QR_LDS_PAIR = QR_LDS_BASE + 256 + 256 + 16;
 constexpr int QR_LDS_DOUBLES = QR_LDS_PAIR + (QR_QUAD ? 7 * 256 + 32 : 0);
@@ -384,8 +384,9 @@ template <int JJ>
 __device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const bool (&rv)[QR_RS], gdbl* Y, long ld,
                                               int j0, ldbl* red, ldbl* tau, ldbl* tot, ldbl* rowb) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  ldbl* totj = tot + 16 * (JJ & 1);
-  ldbl* rowj = rowb + 16 * (JJ & 1);
+  (void)tot;
+  ldbl* redj = red + WG_WAVES * 16 * (JJ & 1);   // partials and pivot row are double buffered by column parity:
+  ldbl* rowj = rowb + 16 * (JJ & 1);             // ONE barrier per column
   constexpr int NV = QR_NB - JJ;           // values to reduce: |x|^2 and NV-1 dots
   if (NV > 8) {
     double vals[16];
@@ -400,7 +401,7 @@ __device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const b
     }
     int idx;
     const double wsum = wave_sum16(vals, lane, idx);
-    if ((lane & 3) == 0) red[wave * 16 + idx] = wsum;
+    if ((lane & 3) == 0) redj[wave * 16 + idx] = wsum;
   } else {
     double vals[8];
 #pragma unroll
@@ -414,20 +415,25 @@ __device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const b
     }
     int idx;
     const double wsum = wave_sum8(vals, lane, idx);
-    if ((lane & 7) == 0) red[wave * 16 + idx] = wsum;
+    if ((lane & 7) == 0) redj[wave * 16 + idx] = wsum;
   }
   if (tid == JJ) {
 #pragma unroll
     for (int c = JJ; c < QR_NB; c++) rowj[c - JJ] = P[0][c];
   }
   __syncthreads();
-  if (tid < NV) {
-    double sacc = 0.0;
+  // every wave sums the partials itself (lane c takes value c) and hands the totals round as wave-uniform values:
+  // no second barrier, no LDS round trip
+  double sacc = 0.0;
+  {
+    const int c = lane & 15;
 #pragma unroll
-    for (int w = 0; w < WG_WAVES; w++) sacc += red[w * 16 + tid];
-    totj[tid] = sacc;
+    for (int w = 0; w < WG_WAVES; w++) sacc += redj[w * 16 + c];
   }
-  __syncthreads();
+  double totj[QR_NB];
+#pragma unroll
+  for (int c = 0; c < NV; c++)
+    totj[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), c), __builtin_amdgcn_readlane(__double2loint(sacc), c));
   const double ss = totj[0];
   const double alpha = rowj[0];
   double beta, tj, scale;
@@ -1251,8 +1257,8 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  ldbl* red = lds;                      // [WG_WAVES*16]
-  ldbl* Ts = lds + WG_WAVES * 16;       // [16*16] T, column-major Ts[i + 16*j]
+  ldbl* red = lds;                      // [2][WG_WAVES*16]
+  ldbl* Ts = lds + 2 * WG_WAVES * 16;   // [16*16] T, column-major Ts[i + 16*j]
   ldbl* tau = Ts + 256;                 // [16]
   ldbl* bc = tau + 16;                  // broadcast scratch [64 + 32]
   const int kmax = min(rows, cols);
