@@ -663,18 +663,17 @@ __device__ __forceinline__ void qr_T_from_gram(const ldbl* big, const ldbl* tau,
     double trow[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      double v = 0.0;
-      if (j < nb) {
-        if (j == tid) v = tau[j];
-        else if (j > tid) {
-          double sacc = 0.0;
+      // column j of G and tau_j are loaded unconditionally, before the dependent sum (trow[i2] = 0 for i2 < tid, so
+      // no predicate on i2 is needed): the loads of the next column overlap the chain of this one
+      double gcol[16];
 #pragma unroll
-          for (int i2 = 0; i2 < 16; i2++)
-            if (i2 >= tid && i2 < j) sacc += trow[i2] * big[i2 + 16 * j];
-          v = -tau[j] * sacc;
-        }
-      }
-      trow[j] = v;
+      for (int i2 = 0; i2 < 16; i2++) gcol[i2] = big[i2 + 16 * j];
+      const double tj = tau[j];
+      double sacc = 0.0;
+#pragma unroll
+      for (int i2 = 0; i2 < j; i2++) sacc += trow[i2] * gcol[i2];
+      double v = (j == tid) ? tj : ((j > tid) ? -tj * sacc : 0.0);
+      trow[j] = (j < nb) ? v : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) Ts[tid + 16 * j] = trow[j];
