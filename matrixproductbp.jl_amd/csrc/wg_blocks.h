@@ -663,15 +663,15 @@ __device__ __forceinline__ void qr_T_from_gram(const ldbl* big, const ldbl* tau,
     double trow[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      // column j of G and tau_j are loaded unconditionally, before the dependent sum (trow[i2] = 0 for i2 < tid, so
-      // no predicate on i2 is needed): the loads of the next column overlap the chain of this one
+      // column j of G and tau_j are loaded unconditionally, before the dependent sum: the loads of the next column
+      // overlap the chain of this one.  (The select on i2 >= tid stays: G entries of unused columns need not be finite.)
       double gcol[16];
 #pragma unroll
       for (int i2 = 0; i2 < 16; i2++) gcol[i2] = big[i2 + 16 * j];
       const double tj = tau[j];
       double sacc = 0.0;
 #pragma unroll
-      for (int i2 = 0; i2 < j; i2++) sacc += trow[i2] * gcol[i2];
+      for (int i2 = 0; i2 < j; i2++) sacc += (i2 >= tid) ? trow[i2] * gcol[i2] : 0.0;
       double v = (j == tid) ? tj : ((j > tid) ? -tj * sacc : 0.0);
       trow[j] = (j < nb) ? v : 0.0;
     }

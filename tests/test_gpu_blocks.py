@@ -61,3 +61,25 @@ def test_jacobi_right_singular_vectors(m, n):
     # A V has orthogonal columns with norms sigma
     W = A @ V
     assert np.abs(W.T @ W - np.diag(sig ** 2)).max() < 1e-12 * s_ref[0] ** 2
+
+
+@pytest.mark.parametrize("variant", ["random", "duplicate_column", "tiny_columns"])
+def test_qr_small_and_degenerate_shapes(variant):
+    """Shapes the engine meets during the first sweeps (bonds 1, 4, 16: a few rows, rows < cols, partial panels)
+    and rank-deficient inputs: R^T R must reproduce A^T A."""
+    import ctypes as C
+    L = mpbp_amd._lib.lib()
+    rng = np.random.default_rng(11)
+    shapes = [(1, 1), (1, 4), (2, 2), (2, 8), (3, 7), (4, 1), (4, 5), (4, 16), (4, 20), (4, 64), (8, 4), (8, 64), (12, 40),
+              (16, 4), (16, 64), (20, 17), (40, 20), (80, 40), (100, 33), (160, 40), (320, 80), (400, 80), (640, 100)]
+    for (r, c) in shapes:
+        A = np.asfortranarray(rng.standard_normal((r, c)))
+        if variant == "duplicate_column" and c > 2:
+            A[:, 1] = A[:, 0]
+        if variant == "tiny_columns":
+            A[:, c // 2:] *= 1e-150
+        R = np.zeros((min(r, c), c), order="F")
+        rc = L.mpbp_selftest_qr(0, r, c, A.ctypes.data_as(C.POINTER(C.c_double)), R.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0 and np.isfinite(R).all(), (r, c)
+        G1, G2 = R.T @ R, A.T @ A
+        assert np.abs(G1 - G2).max() <= 1e-12 * max(np.abs(G2).max(), 1e-300), (r, c, variant)
