@@ -1403,6 +1403,50 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
 // `red`: >= 16 doubles; `act`: >= n ints of LDS.  Returns the number of sweeps, or -1 if not converged.
 // lda / ldv should be odd (LDS bank spreading between the column pairs of different lane groups).
 // ---------------------------------------------------------------------------------------------
+// Jacobi rotation that orthogonalises two columns with squared norms al, be and inner product ga:
+// t = tan(theta) = sgn(d) 2 ga / (|d| + sqrt(d^2 + 4 ga^2)), d = be - al  (smaller root); c = 1/sqrt(1 + t^2), s = c t:
+// one sqrt, one reciprocal, one rsqrt - hardware seeds refined by Newton steps (the plain IEEE division / sqrt
+// sequences dominate the cost of a rotation otherwise)
+__device__ __forceinline__ void jac_cs(double al, double be, double ga, double& c, double& s) {
+  const double d = be - al, g2 = 2.0 * ga;
+  const double h2 = d * d + g2 * g2;
+  double rs = __builtin_amdgcn_rsq(h2);
+  rs = rs * (1.5 - 0.5 * h2 * rs * rs);
+  double hy = h2 * rs;                                   // sqrt(h2)
+  hy = hy + 0.5 * rs * (h2 - hy * hy);
+  const double den = fabs(d) + hy;
+  double rd = __builtin_amdgcn_rcp(den);
+  rd = rd * (2.0 - den * rd);
+  rd = rd * (2.0 - den * rd);
+  const double t = copysign(g2, d * ga) * rd;
+  const double o2 = 1.0 + t * t;
+  c = __builtin_amdgcn_rsq(o2);
+  c = c * (1.5 - 0.5 * o2 * c * c);
+  c = c * (1.5 - 0.5 * o2 * c * c);
+  s = c * t;
+}
+
+// One column pair handled by 8 lanes when the column length is exactly 8 R: no predicates, no address selects, the
+// columns stay in registers between the dot products and the rotation.  Returns cos^2 of the angle if it rotated.
+template <int R, class AP>
+__device__ __forceinline__ double jac_pair8(AP ap, AP aq, int sub, double tol, double nul) {
+  double x[R], y[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) { x[i] = ap[sub + 8 * i]; y[i] = aq[sub + 8 * i]; }
+  double al = 0, be = 0, ga = 0;
+#pragma unroll
+  for (int i = 0; i < R; i++) { al += x[i] * x[i]; be += y[i] * y[i]; ga += x[i] * y[i]; }
+  al += dpp64<0x141>(al); be += dpp64<0x141>(be); ga += dpp64<0x141>(ga);
+  al += dpp64<0x4E>(al); be += dpp64<0x4E>(be); ga += dpp64<0x4E>(ga);
+  al += dpp64<0xB1>(al); be += dpp64<0xB1>(be); ga += dpp64<0xB1>(ga);
+  if (!(ga * ga > (tol * tol) * (al * be) && al > nul && be > nul)) return 0.0;
+  double c, s;
+  jac_cs(al, be, ga, c, s);
+#pragma unroll
+  for (int i = 0; i < R; i++) { ap[sub + 8 * i] = c * x[i] - s * y[i]; aq[sub + 8 * i] = s * x[i] + c * y[i]; }
+  return ga * ga / (al * be);
+}
+
 template <class AP>     // AP = ldbl* (matrix in LDS) or gdbl* (in HBM): typed so that the inner loops are ds_* / global_*
 __device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n, double* V, int ldv, ldbl* red,
                                                     __attribute__((address_space(3))) int* act, int maxsweeps) {
@@ -1437,6 +1481,7 @@ __device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n,
     const int sub = tid & (LP - 1);       // lane inside the pair group
     const int grp = tid >> lg;
     const int rpl = (m + LP - 1) >> lg;   // rows per lane
+    const bool exact8 = !V && lg == 3 && m == 8 * rpl && (rpl == 2 || rpl == 4 || rpl == 6 || rpl == 8 || rpl == 10 || rpl == 12);
     double worst = 0.0;                   // largest cos^2 of the angle between two columns met in this sweep
     for (int round = 0; round < ne - 1; round++) {
       for (int pb = 0; pb < npairs; pb += WG_THREADS >> lg) {
@@ -1454,6 +1499,19 @@ __device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n,
             const int cp = act[p], cq = act[q];
             AP ap = A + (long)lda * cp;
             AP aq = A + (long)lda * cq;
+            if (exact8) {          // the common shapes: 8 lanes per pair, column length a multiple of 8 (wave-uniform)
+              double w2 = 0.0;
+              switch (rpl) {
+                case 2: w2 = jac_pair8<2>(ap, aq, sub, tol, nul); break;
+                case 4: w2 = jac_pair8<4>(ap, aq, sub, tol, nul); break;
+                case 6: w2 = jac_pair8<6>(ap, aq, sub, tol, nul); break;
+                case 8: w2 = jac_pair8<8>(ap, aq, sub, tol, nul); break;
+                case 10: w2 = jac_pair8<10>(ap, aq, sub, tol, nul); break;
+                default: w2 = jac_pair8<12>(ap, aq, sub, tol, nul); break;
+              }
+              worst = fmax(worst, w2);
+              continue;
+            }
             // rows r = sub + LP*i of the two columns, JC per lane at a time with all loads in flight together
             // (a single wave has no second wave to hide the LDS latency); when the whole column fits the JC
             // registers the rotation reuses them instead of reading the columns again
@@ -1480,25 +1538,8 @@ __device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n,
             if (lg >= 1) { al += dpp64<0xB1>(al); be += dpp64<0xB1>(be); ga += dpp64<0xB1>(ga); }
             if (ga * ga > (tol * tol) * (al * be) && al > nul && be > nul) {
               worst = fmax(worst, ga * ga / (al * be));
-              // t = tan(theta) = sgn(d) 2 ga / (|d| + sqrt(d^2 + 4 ga^2)), d = be - al  (smaller root);
-              // c = 1/sqrt(1 + t^2), s = c t: one sqrt, one reciprocal, one rsqrt - hardware seeds refined by
-              // Newton steps (the plain IEEE division / sqrt sequences dominate the cost of a rotation otherwise)
-              const double d = be - al, g2 = 2.0 * ga;
-              const double h2 = d * d + g2 * g2;
-              double rs = __builtin_amdgcn_rsq(h2);
-              rs = rs * (1.5 - 0.5 * h2 * rs * rs);
-              double hy = h2 * rs;                                   // sqrt(h2)
-              hy = hy + 0.5 * rs * (h2 - hy * hy);
-              const double den = fabs(d) + hy;
-              double rd = __builtin_amdgcn_rcp(den);
-              rd = rd * (2.0 - den * rd);
-              rd = rd * (2.0 - den * rd);
-              const double t = copysign(g2, d * ga) * rd;
-              const double o2 = 1.0 + t * t;
-              double c = __builtin_amdgcn_rsq(o2);
-              c = c * (1.5 - 0.5 * o2 * c * c);
-              c = c * (1.5 - 0.5 * o2 * c * c);
-              const double s = c * t;
+              double c, s;
+              jac_cs(al, be, ga, c, s);
               for (int i0 = 0; i0 < rpl; i0 += JC) {
                 if (rpl > JC) loadc(i0);
 #pragma unroll
