@@ -306,6 +306,7 @@ constexpr int QR_NB = 16;
 constexpr int QR_RS = 4;      // rows per thread of the register panel
 constexpr int QR_TC = 3;      // column tiles a wave updates together
 constexpr int QR_LDS_BASE = 2 * WG_WAVES * 16 + 16 * 16 + 16 + 2 * 32 + 2 * 16;   // [red x2][Ts][tau][bc]
+constexpr int QR_ROWPAR_TILES = 1;   // trailing tiles at or below which a 4-panel update runs row-parallel (one tile at a time)
 constexpr bool QR_QUAD = (WG_THREADS == 512);   // aggregate four panels (K = 64 trailing updates) - 512-thread variant only
 constexpr int QR_LDS_PAIR = QR_LDS_BASE + 256 + 256 + 16;
 constexpr int QR_LDS_DOUBLES = QR_LDS_PAIR + (QR_QUAD ? 7 * 256 + 32 : 0);
@@ -1251,6 +1252,104 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
   }
 }
 
+// Row-parallel counterpart of qr_trail4<1>: ONE 16-column tile updated by the four panels at j0 with all waves
+// working on different rows (partials of V_p^T C through LDS).  Used for the last tiles of a factorisation, when
+// there are fewer tiles than waves and the tile-per-wave split would leave most of the workgroup idle.
+// `big`: WG_WAVES * 1024 doubles.
+__device__ __forceinline__ void qr_tile_update4_all(gdbl* Y, long ld, int rows32, int j0, int cb0,
+                                                    const ldbl* const (&Tq)[4], const ldbl* const (&Sq)[6], ldbl* big) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nrb = (rows32 - j0) >> 4;
+  const gdbl* vcol[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) vcol[p] = Y + (long)(j0 + 16 * p + l15) * ld + j0 + 4 * g;
+  const gdbl* ccol = Y + (long)(cb0 + l15) * ld + j0 + 4 * g;
+  d4 acc[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) acc[p] = d4{0, 0, 0, 0};
+  for (int rb = wave; rb < nrb; rb += WG_WAVES) {
+    d4 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) v[p] = *reinterpret_cast<const gd4*>(vcol[p] + 16 * rb);
+    const d4 c = *reinterpret_cast<const gd4*>(ccol + 16 * rb);
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int rho = 4 * g + e;
+        double a = v[p][e];
+        a = (rb == p) ? ((rho > l15) ? a : ((rho == l15) ? 1.0 : 0.0)) : a;
+        v[p][e] = (rb >= p) ? a : 0.0;
+      }
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int p = 0; p < 4; p++) acc[p] = mfma(v[p][e], c[e], acc[p]);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) big[wave * 1024 + 256 * p + (g + 4 * r) + 16 * l15] = acc[p][r];
+  __syncthreads();
+  d4 w[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    d4 t = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int w2 = 0; w2 < WG_WAVES; w2++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) t[r] += big[w2 * 1024 + 256 * p + (g + 4 * r) + 16 * l15];
+#pragma unroll
+    for (int r = 0; r < p; r++) {
+      const ldbl* S = Sq[p * (p - 1) / 2 + r];
+#pragma unroll
+      for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][s], t);
+    }
+    d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) o = mfma(Tq[p][(4 * s + g) + 16 * l15], t[s], o);
+    w[p] = o;
+  }
+  const int jb = j0 & ~31;
+  const int nst = (rows32 - jb) >> 5;
+  for (int st = wave; st < nst; st += WG_WAVES) {
+    const int row = jb + 32 * st + 2 * l15;
+    d2 v[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        const int k = 4 * s2 + g;
+        d2 x = *reinterpret_cast<const gd2*>(Y + (long)(j0 + 16 * p + k) * ld + row);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int rp = row + e - j0 - 16 * p;
+          double a = x[e];
+          a = (rp < 16) ? ((rp > k) ? a : ((rp == k) ? 1.0 : 0.0)) : a;
+          x[e] = (rp >= 0) ? a : 0.0;
+        }
+        v[p][s2] = x;
+      }
+    d2 c[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      d4 a4 = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) a4 = mfma(-w[p][s2], v[p][s2][e], a4);
+#pragma unroll
+      for (int r = 0; r < 4; r++) c[r][e] = a4[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) *reinterpret_cast<gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row) = c[r];
+  }
+  __syncthreads();
+}
+
 // `big`: >= WG_WAVES*1024 doubles of LDS scratch when QR_QUAD (else WG_WAVES*512); may alias the gemm tile buffers
 __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
@@ -1343,12 +1442,18 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
       factor_pair2(j0);
       const ldbl* const Tq[4] = {Ts, TsB, TsC, TsD};
       const ldbl* const Sq[6] = {Sm, Sca, Scb, Sda, Sdb, Sdc};
-      int tstart, tcnt;
-      wave_tiles(j0 + 64, tstart, tcnt);
-      for (int tg = 0; tg < tcnt; tg += 2) {
-        const int cb0 = j0 + 64 + (tstart + tg) * 16;
-        if (tcnt - tg >= 2) qr_trail4<2>(Y, ld, rows32, j0, cb0, Tq, Sq);
-        else qr_trail4<1>(Y, ld, rows32, j0, cb0, Tq, Sq);
+      const int ntl4 = (cols - (j0 + 64) + 15) / 16;
+      if (WG_WAVES > 1 && ntl4 <= QR_ROWPAR_TILES) {
+        // few tiles left: one tile at a time, rows shared out to all waves
+        for (int tl = 0; tl < ntl4; tl++) qr_tile_update4_all(Y, ld, rows32, j0, j0 + 64 + 16 * tl, Tq, Sq, big);
+      } else {
+        int tstart, tcnt;
+        wave_tiles(j0 + 64, tstart, tcnt);
+        for (int tg = 0; tg < tcnt; tg += 2) {
+          const int cb0 = j0 + 64 + (tstart + tg) * 16;
+          if (tcnt - tg >= 2) qr_trail4<2>(Y, ld, rows32, j0, cb0, Tq, Sq);
+          else qr_trail4<1>(Y, ld, rows32, j0, cb0, Tq, Sq);
+        }
       }
       __syncthreads();
       if (pr) prof_mark(pr, *plast, fine ? 18 : ph_trail);
