@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpbp_hip.so")
 SOURCES = ["mpbp_hip.hip"]
-HEADERS = ["kernels.h", "engine.h", "wg_blocks.h", os.path.join("..", "..", "include", "mpbp_hip.h")]
+HEADERS = ["kernels.h", "engine.h", "engine_types.h", "wg_blocks.h", "wg_common.h",
+           os.path.join("..", "..", "include", "mpbp_hip.h")]
 
 MPBP_TRUNC_THRESH, MPBP_TRUNC_BOND, MPBP_TRUNC_BOND_MAX, MPBP_TRUNC_BOND_THRESH = 0, 1, 2, 3
 
@@ -72,13 +73,18 @@ _lib = None
 
 
 def lib():
-    """Load (never build implicitly on a box without sources newer than the binary)."""
+    """Load the library (compiling it first if the binary is missing)."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise MPBPError(-100, f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # a fresh checkout: compile the library once (this is the product itself, not a fallback)
+        try:
+            build()
+        except Exception as e:           # no hipcc, or the compile failed
+            raise MPBPError(-100, f"{LIB_PATH} not found and could not be built ({e}): run "
+                                  "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
+                                  "There is no CPU fallback.") from e
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(L, name):
