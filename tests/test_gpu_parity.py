@@ -1,6 +1,9 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle on the same inputs, and with the
 reference's own known answers.  Tolerance: 1e-6 relative (BASELINE.json north_star); most cases are
 checked far tighter because the device algorithm is backward stable."""
+import os
+import sys
+
 import networkx as nx
 import numpy as np
 import pytest
@@ -481,3 +484,13 @@ def test_more_observables_match_enumeration_and_oracle():
     M.iterate(bp, maxiter=10, svd_trunc=M.TruncBondMax(4), schedule="colored")
     b = M.beliefs(bp)
     assert abs(b[0][0][1] - 0.5) < 1e-9        # free dynamics: the time-0 marginal is uniform after reset_observations
+
+
+def test_randomised_models_graphs_truncations():
+    """tools/fuzz.py: 40 random cases (graph, SIS / SIRS / Glauber variants, T, bond cap, SVDTrunc rule, damping,
+    number of sweeps) against the oracle; beliefs, pair beliefs and free energy within 1e-6 (observed <= 2e-12)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "40", "123"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
