@@ -491,6 +491,7 @@ def test_randomised_models_graphs_truncations():
     number of sweeps) against the oracle; beliefs, pair beliefs and free energy within 1e-6 (observed <= 2e-12)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "40", "123"], capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    for args in (["40", "123"], ["10", "5", "big"]):       # "big": bond caps 10..18 (2- and 4-panel QR paths)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py")] + args, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

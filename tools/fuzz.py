@@ -1,6 +1,6 @@
 """Randomised parity check of the device path against the numpy oracle: random small graphs, models (SIS, SIRS,
 homogeneous / +-J Glauber), chain lengths, bond caps, truncation rules, damping and schedules.  Test infrastructure
-(imports oracle/); usage: python tools/fuzz.py [n_cases] [seed]."""
+(imports oracle/); usage: python tools/fuzz.py [n_cases] [seed] [big]."""
 import os
 import sys
 
@@ -14,6 +14,7 @@ import oracle.tensor_trains as OT
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"      # bond caps 10..18: the 2- and 4-panel QR paths of the 512-thread engine
 rng = np.random.default_rng(seed)
 
 
@@ -30,11 +31,13 @@ for case in range(n_cases):
     N = int(rng.integers(3, 9))
     T = int(rng.integers(1, 7))
     Mb = int(rng.integers(2, 10))
+    if big:
+        N, T, Mb = int(rng.integers(4, 7)), int(rng.integers(4, 9)), int(rng.integers(10, 19))
     A = random_graph(N)
-    model = rng.choice(["sis", "sirs", "glauber_h", "glauber_pmj"])
+    model = rng.choice(["sis", "sirs", "glauber_h", "glauber_pmj"]) if not big else rng.choice(["sis", "glauber_h"])
     damp = float(rng.choice([0.0, 0.0, 0.3]))
     kind = rng.choice(["bond", "bondmax", "thresh", "bondthresh"])
-    sweeps = int(rng.integers(1, 4))
+    sweeps = int(rng.integers(1, 4)) if not big else 3
     if model == "sis":
         q, par = 2, (rng.uniform(0.05, 0.6), rng.uniform(0.05, 0.6), rng.uniform(0, 0.2))
         w = [[M.SISFactor(*par)] * (T + 1)] * N
