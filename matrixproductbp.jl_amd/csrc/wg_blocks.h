@@ -78,40 +78,52 @@ __device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* 
 #pragma unroll
       for (int t = 0; t < 6; t++) acc[t] = d4{0, 0, 0, 0};
       const bool w_act = wave * 16 < ncols;
-      for (int k0 = 0; k0 < K; k0 += GM_KC) {
-        // ---- stage S tile: As[kk][i]
-        if (s_act) {
+      // Register double buffering: the global loads of chunk k0 + GM_KC are issued before the MFMAs of chunk k0
+      // and only written to LDS after them (branch-free clamped loads + selects, so that they stay in flight).
+      double sv[4], xv[4];
+      auto load_chunk = [&](int k0) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            int kk = (tid >> 7) + 4 * e;
-            double v = 0.0;
-            if (s_in && k0 + kk < K) v = Sp[s_ro + (long)sco(k0 + kk)];
-            As[kk * GM_LDA + si] = v;
-          }
+        for (int e = 0; e < 4; e++) {
+          const int kk = (tid >> 7) + 4 * e;
+          const bool ok = s_in && k0 + kk < K;
+          const double v = Sp[s_ro + (long)sco(ok ? k0 + kk : 0)];
+          sv[e] = ok ? v : 0.0;
         }
-        // ---- stage X tile: Bs[kk][j]
         if (xkfast) {
-          int kk = tid & 15;
-          bool kin = k0 + kk < K;
-          long r = kin ? (long)xro(k0 + kk) : 0;
+          const int kk = tid & 15;
+          const bool kin = k0 + kk < K;
+          const long r = (long)xro(kin ? k0 + kk : 0);
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            int j = (tid >> 4) + 32 * e;
-            double v = 0.0;
-            if (kin && x_in[e]) v = Xp[r + x_co[e]];
-            Bs[kk * GM_LDB + j] = v;
+            const double v = Xp[r + x_co[e]];
+            xv[e] = (kin && x_in[e]) ? v : 0.0;
           }
         } else {
-          int j = tid & 127;
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            int kk = (tid >> 7) + 4 * e;
-            double v = 0.0;
-            if (x_in[0] && k0 + kk < K) v = Xp[(long)xro(k0 + kk) + x_co[0]];
-            Bs[kk * GM_LDB + j] = v;
+            const int kk = (tid >> 7) + 4 * e;
+            const bool ok = x_in[0] && k0 + kk < K;
+            const double v = Xp[(long)xro(ok ? k0 + kk : 0) + x_co[0]];
+            xv[e] = ok ? v : 0.0;
           }
         }
+      };
+      load_chunk(0);
+      for (int k0 = 0; k0 < K; k0 += GM_KC) {
+        // ---- stage the S tile As[kk][i] and the X tile Bs[kk][j] from the registers
+        if (s_act) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) As[((tid >> 7) + 4 * e) * GM_LDA + si] = sv[e];
+        }
+        if (xkfast) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) Bs[(tid & 15) * GM_LDB + (tid >> 4) + 32 * e] = xv[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) Bs[((tid >> 7) + 4 * e) * GM_LDB + (tid & 127)] = xv[e];
+        }
         __syncthreads();
+        if (k0 + GM_KC < K) load_chunk(k0 + GM_KC);
         if (w_act) {
 #pragma unroll
           for (int ks = 0; ks < GM_KC / 4; ks++) {
