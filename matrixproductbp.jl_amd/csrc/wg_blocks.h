@@ -220,7 +220,8 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
 #pragma unroll
           for (int t = 0; t < 6; t++) {
             if (t < ntm) {
-              const double a = (s_in[t] && kin[u]) ? Sp[s_ro[t] + so[u]] : 0.0;
+              const double av = Sp[s_ro[t] + so[u]];          // always a valid address (clamped maps): load, then mask
+              const double a = (s_in[t] && kin[u]) ? av : 0.0;
               acc[t] = mfma(a, bv, acc[t]);
             }
           }
