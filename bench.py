@@ -225,9 +225,12 @@ def main():
                     "avg_launch_ms": (t_orth / launches * 1e3) if launches else None,
                     "flops_per_launch_executed": ex / launches if launches else None,
                     "achieved_reference_algorithmic": refalg / t_orth / 1e12 if t_orth > 0 else 0.0,
-                    "note": "achieved counts the flops the engine executes (structured contractions + R-only "
-                            "Householder QR); achieved_reference_algorithmic prices the same launches with the "
-                            "reference algorithm's SVD-based flop count (SURVEY.md 8d)"}
+                    "frac_reference_algorithmic": (refalg / t_orth / 1e12 / FP64_PEAK_TFLOPS) if t_orth > 0 else 0.0,
+                    "note": "achieved / frac count the flops the engine executes (structured contractions + R-only "
+                            "Householder QR + Jacobi on the small factor): the conservative, hardware-utilisation "
+                            "reading; *_reference_algorithmic price the same launches with SURVEY.md 8(d)'s count for "
+                            "the reference algorithm (SVD-based, 601.6 Gflop per node), which the device path "
+                            "legitimately undercuts and which can therefore exceed the peak"}
         out = {"metric": "edge-message updates/sec (and s/sweep), SIS 3-regular N=1024 T=50 d=20",
                "value": value, "unit": "edge-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "s_per_sweep": ms_per_step / 1e3, "higher_is_better": True,
