@@ -495,3 +495,19 @@ def test_randomised_models_graphs_truncations():
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py")] + args, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_baseline_config0_glauber_3node_path_exact_gpu():
+    """BASELINE.json configs[0]: Glauber on the 3-node path, T = 3, TruncBond(4), against enumeration (1e-8)."""
+    T = 3
+    J = np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]], float)
+    h = np.random.default_rng(0).standard_normal(3)
+    phi = [[np.array([0.75, 0.25]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(3)]
+    gl = M.Glauber(M.Ising(J, h, 1.0), T, phi=phi)
+    bp = gl.mpbp(max_bond=4)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBond(4), schedule="sequential")
+    obp = O.mpbp(O.IndexedBiDiGraph(J != 0), OF.glauber_factors(J != 0, J, h, 1.0, T), [2] * 3, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-8
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-8

@@ -276,3 +276,20 @@ def test_infinite_graph_equals_complete_graph():
     iterate(bp, maxiter=30, svd_trunc=TruncBond(16), tol=1e-15)
     assert _maxerr(beliefs(bpi)[0], beliefs(bp)[0]) < 1e-9
     assert abs(bethe_free_energy(bpi) - bethe_free_energy(bp) / 3) < 1e-9
+
+
+def test_baseline_config0_glauber_3node_path_exact():
+    """BASELINE.json configs[0] / SURVEY 8(d) config 1: Glauber on the 3-node path, J = 1, beta = 1, seeded fields,
+    T = 3, TruncBond(4): must equal brute-force enumeration to 1e-8."""
+    T = 3
+    J = np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]], float)
+    h = np.random.default_rng(0).standard_normal(3)
+    phi = [[np.array([0.75, 0.25]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(3)]
+    import oracle.factors as OF
+    import oracle.mpbp as O
+    bp = O.mpbp(O.IndexedBiDiGraph(J != 0), OF.glauber_factors(J != 0, J, h, 1.0, T), [2] * 3, T, phi=phi)
+    O.iterate(bp, maxiter=10, svd_trunc=TruncBond(4), tol=0.0, shuffle_nodes=False)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(bp)
+    assert np.abs(np.array(O.beliefs(bp)) - np.array(exact_marginals(bp, p))).max() < 1e-8
+    assert abs(np.exp(-O.bethe_free_energy(bp)) - Z) / Z < 1e-8
