@@ -195,55 +195,76 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
       s_in[t] = t < ntm && i < mrows;
       s_ro[t] = s_in[t] ? (long)sro(mb + i) : 0;
     }
-    for (int tl = wave; tl < ntile; tl += WG_WAVES) {
-      const int j = tl * 16 + l15;
-      const bool jin = j < N;
-      const long cofs = jin ? (long)xco(j) : 0;
-      d4 acc[6];
+    // Software pipeline over (tile, group of 5 k-steps): the X loads of the next group - of this tile or of the
+    // wave's next tile - are issued before the MFMAs of the current one.  (Measured at low occupancy these
+    // contractions are latency bound, not bandwidth bound.)
+    struct Grp { double b[5]; long so[5]; unsigned kin; };
+    auto fetch = [&](long cofs, int ks0, Grp& G) {
+      G.kin = 0;
 #pragma unroll
-      for (int t = 0; t < 6; t++) acc[t] = d4{0, 0, 0, 0};
-      for (int ks0 = 0; ks0 < nks; ks0 += 5) {
-        double b[5];
-        long so[5];
-        bool kin[5];
+      for (int u = 0; u < 5; u++) {
+        const int k = 4 * (ks0 + u) + g;
+        const bool kin = (ks0 + u < nks) && k < K;
+        const int kc = kin ? k : 0;
+        G.b[u] = NTX ? __builtin_nontemporal_load(Xp + ((long)xro(kc) + cofs)) : Xp[(long)xro(kc) + cofs];   // valid address, masked later
+        G.so[u] = (long)sco(kc);
+        G.kin |= kin ? (1u << u) : 0u;
+      }
+    };
+    int tl = wave;
+    if (tl < ntile) {
+      int j = tl * 16 + l15;
+      bool jin = j < N;
+      long cofs = jin ? (long)xco(j) : 0;
+      Grp cur, nxt;
+      fetch(cofs, 0, cur);
+      for (;;) {
+        d4 acc[6];
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
-          const int k = 4 * (ks0 + u) + g;
-          kin[u] = (ks0 + u < nks) && k < K;
-          const int kc = kin[u] ? k : 0;
-          b[u] = NTX ? __builtin_nontemporal_load(Xp + ((long)xro(kc) + cofs)) : Xp[(long)xro(kc) + cofs];   // unconditional (valid address), masked below
-          so[u] = (long)sco(kc);
+        for (int t = 0; t < 6; t++) acc[t] = d4{0, 0, 0, 0};
+        const int tl2 = tl + WG_WAVES;
+        const int j2 = tl2 * 16 + l15;
+        const bool jin2 = j2 < N;
+        long cofs2 = 0;
+        for (int ks0 = 0; ks0 < nks; ks0 += 5) {
+          if (ks0 + 5 < nks) fetch(cofs, ks0 + 5, nxt);                 // wave-uniform branches
+          else if (tl2 < ntile) { cofs2 = jin2 ? (long)xco(j2) : 0; fetch(cofs2, 0, nxt); }
+#pragma unroll
+          for (int u = 0; u < 5; u++) {
+            const bool kin = (cur.kin >> u) & 1u;
+            const double bv = (kin && jin) ? cur.b[u] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+              if (t < ntm) {
+                const double av = Sp[s_ro[t] + cur.so[u]];          // always a valid address (clamped maps): load, then mask
+                const double a = (s_in[t] && kin) ? av : 0.0;
+                acc[t] = mfma(a, bv, acc[t]);
+              }
+            }
+          }
+          cur = nxt;
         }
-#pragma unroll
-        for (int u = 0; u < 5; u++) {
-          const double bv = (kin[u] && jin) ? b[u] : 0.0;
+        if (jin) {
+          const long oc = (long)oco(j);
 #pragma unroll
           for (int t = 0; t < 6; t++) {
             if (t < ntm) {
-              const double av = Sp[s_ro[t] + so[u]];          // always a valid address (clamped maps): load, then mask
-              const double a = (s_in[t] && kin[u]) ? av : 0.0;
-              acc[t] = mfma(a, bv, acc[t]);
-            }
-          }
-        }
-      }
-      if (jin) {
-        const long oc = (long)oco(j);
 #pragma unroll
-        for (int t = 0; t < 6; t++) {
-          if (t < ntm) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int row = t * 16 + g + 4 * r;
-              if (row < mrows) {
-                OP p = Op + (long)oro(mb + row) + oc;
-                double v = acc[t][r];
-                if (accumulate) v += *p;
-                if (NTO) __builtin_nontemporal_store(v, p); else *p = v;
+              for (int r = 0; r < 4; r++) {
+                const int row = t * 16 + g + 4 * r;
+                if (row < mrows) {
+                  OP p = Op + (long)oro(mb + row) + oc;
+                  double v = acc[t][r];
+                  if (accumulate) v += *p;
+                  if (NTO) __builtin_nontemporal_store(v, p); else *p = v;
+                }
               }
             }
           }
         }
+        tl = tl2;
+        if (tl >= ntile) break;
+        j = j2; jin = jin2; cofs = cofs2;
       }
     }
   }
