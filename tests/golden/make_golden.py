@@ -31,8 +31,7 @@ def known_answer():
                "beliefs": ref}, open(os.path.join(HERE, "sis_infinite_graph_reference.json"), "w"), indent=1)
 
 
-def rrg_sweeps():
-    N, T, Mb, sweeps = 16, 10, 8, 3
+def rrg_sweeps(N=16, T=10, Mb=8, sweeps=3, name="sis_rrg16_T10_M8_jacobi.npz"):
     lam, rho, gam = 0.1, 0.05, 0.1
     A = nx.to_numpy_array(nx.random_regular_graph(3, N, seed=0), nodelist=range(N))
     phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
@@ -46,7 +45,7 @@ def rrg_sweeps():
     out["pair_beliefs"] = np.array(pb)
     out["pair_logz"] = lz
     out["bonds"] = np.array([m.bonds for m in bp.mu])
-    np.savez_compressed(os.path.join(HERE, "sis_rrg16_T10_M8_jacobi.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, name), **out)
 
 
 def star_exact():
@@ -69,4 +68,8 @@ if __name__ == "__main__":
     known_answer()
     rrg_sweeps()
     star_exact()
+    if "--production-dims" in sys.argv:
+        # BASELINE configs[1] dimensions (T = 50, TruncBond(20): product bond 400) on 8 nodes; the oracle needs about
+        # 100 s per saturated sweep, so this one is only regenerated on request
+        rrg_sweeps(8, 50, 20, 5, "sis_rrg8_T50_M20_jacobi.npz")
     print(sorted(os.listdir(HERE)))
