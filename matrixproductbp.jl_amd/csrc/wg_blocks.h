@@ -1289,8 +1289,9 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
 // Row-parallel counterpart of qr_trail4<1>: ONE 16-column tile updated by the four panels at j0 with all waves
 // working on different rows (partials of V_p^T C through LDS).  Used for the last tiles of a factorisation, when
 // there are fewer tiles than waves and the tile-per-wave split would leave most of the workgroup idle.
-// `big`: WG_WAVES * 1024 doubles.
-__device__ __forceinline__ void qr_tile_update4_all(gdbl* Y, long ld, int rows32, int j0, int cb0,
+// `big`: WG_WAVES * 1024 doubles.  noinline on purpose: inlined into qr_r (which sits at the 256-register limit) one
+// build of this function was observed to return wrong results although its source had not changed.
+__device__ __attribute__((noinline)) void qr_tile_update4_all(gdbl* Y, long ld, int rows32, int j0, int cb0,
                                                     const ldbl* const (&Tq)[4], const ldbl* const (&Sq)[6], ldbl* big) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
