@@ -188,6 +188,10 @@ int mpbp_selftest_jacobi_bench(int32_t device, int32_t m, int32_t n, int32_t nbl
                                int32_t reps, double* ms_out, double* avg_sweeps);
 int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, const double* A, double* sigma,
                       double* V);
+/* nprob independent rows x cols matrices (A: [nprob][rows x cols] column-major) through the grid-level batched QR of
+ * the gauge sweep (csrc/v2_kernels.h); R: [nprob][min(rows,cols) x cols]; force_tall: column-step panels always. */
+int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t cols, int32_t nprob, int32_t force_tall,
+                             const double* A, double* R, double* ms_out);
 
 #ifdef __cplusplus
 }

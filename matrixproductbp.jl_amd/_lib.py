@@ -9,8 +9,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpbp_hip.so")
-SOURCES = ["mpbp_hip.hip"]
-HEADERS = ["kernels.h", "engine.h", "engine_types.h", "wg_blocks.h", "wg_common.h",
+SOURCES = ["mpbp_hip.hip", "v2_engine.hip"]
+HEADERS = ["kernels.h", "engine.h", "engine_types.h", "wg_blocks.h", "wg_common.h", "ctx.h", "v2_kernels.h", "v2_engine.h",
            os.path.join("..", "..", "include", "mpbp_hip.h")]
 
 MPBP_TRUNC_THRESH, MPBP_TRUNC_BOND, MPBP_TRUNC_BOND_MAX, MPBP_TRUNC_BOND_THRESH = 0, 1, 2, 3
@@ -50,22 +50,34 @@ EXPORTS = ["mpbp_create", "mpbp_destroy", "mpbp_last_error", "mpbp_slab_layout",
            "mpbp_set_factor", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
            "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_get_belief_train", "mpbp_pair_beliefs",
            "mpbp_free_energy", "mpbp_logz", "mpbp_set_profiling", "mpbp_phase_profile", "mpbp_selftest_gemm", "mpbp_selftest_qr", "mpbp_selftest_qr_bench",
-           "mpbp_selftest_jacobi_bench", "mpbp_selftest_svd"]
+           "mpbp_selftest_jacobi_bench", "mpbp_selftest_svd", "mpbp_selftest_qr_batched"]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value",
-           "-shared", "-fPIC", "-o", LIB_PATH] + srcs
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    if verbose:
-        print(r.stderr)
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per source
+    (compiled concurrently, only when stale), then one link."""
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-fPIC"]
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        deps = [src] + hdrs
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in deps):
+            procs.append((s, subprocess.Popen(["hipcc"] + flags + ["-c", "-o", obj, src], stdout=subprocess.PIPE,
+                                              stderr=subprocess.STDOUT, text=True)))
+    for s, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n" + out)
+        if verbose:
+            print(out)
+    if procs or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(o) for o in objs):
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     return LIB_PATH
 
 
@@ -116,6 +128,7 @@ def lib():
     L.mpbp_selftest_qr.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp]
     L.mpbp_selftest_qr_bench.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp]
     L.mpbp_selftest_svd.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
+    L.mpbp_selftest_qr_batched.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
     _lib = L
     return L
 

@@ -3,100 +3,9 @@
 // reference src/recursive_bp_factor.jl:49-54), unroll CavityTools.cavity into a levelled DAG of `op`s
 // (src/recursive_bp_factor.jl:140), lay trains out in HBM and launch the kernels of kernels.h.
 #include "kernels.h"
+#include "ctx.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-static thread_local std::string g_create_error;
-
-#define HIPCHK(ctx, call)                                                                         \
-  do {                                                                                            \
-    hipError_t e_ = (call);                                                                       \
-    if (e_ != hipSuccess) {                                                                       \
-      return (ctx)->fail(MPBP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    }                                                                                             \
-  } while (0)
-
-namespace {
-
-struct DevTrain {       // a tensor train resident in HBM
-  double* cores = nullptr; int32_t* bonds = nullptr; double* logz = nullptr;
-  int64_t stride = 0;   // doubles between cores
-  int cap = 0, ny = 0, d = 0, level = 0;
-};
-
-struct NodeFactor {
-  bool set = false; int deg = 0, nt = 1;
-  std::vector<int> ny;
-  std::vector<double> prob_y, prob_xy, prob_yy, prob_y0;
-  std::vector<int64_t> yy_off;   // offset of block (d1,d2) inside one time block of prob_yy
-  int64_t yy_tblock = 0;
-};
-
-// bump allocator over one device arena, regrown on demand between sweeps
-struct Arena {
-  char* base = nullptr; size_t cap = 0, used = 0, want = 0;
-  void reset() { used = 0; want = 0; }
-  void* take(size_t bytes) {
-    size_t a = (bytes + 255) & ~size_t(255);
-    want += a;
-    if (used + a > cap) { return nullptr; }
-    void* p = base + used; used += a; return p;
-  }
-};
-
-}  // namespace
-
-struct mpbp_ctx {
-  int N = 0, E = 0, T = 0, L = 0, q = 0, cap = 0, device = 0, nslots = 0;
-  std::vector<int> nbr_ptr, in_edge, out_edge, slot_of_edge;
-  std::vector<NodeFactor> fac;
-  std::vector<double> phi, psi;           // host copies (ABI layouts)
-  bool own_cores = false, own_bonds = false, own_stream = false;
-  double* d_cores = nullptr; int32_t* d_bonds = nullptr;
-  int64_t core_stride = 0, slot_doubles = 0;
-  hipStream_t stream = nullptr;
-  // persistent outputs
-  double* d_beliefs = nullptr;    // [q][L][N]
-  double* d_btrain = nullptr; int32_t* d_bbond = nullptr;   // normalised belief trains (MPEM1, bond <= q*cap), optional
-  int64_t bt_stride = 0, bt_slot = 0;
-  double* d_logz_node = nullptr;  // [N]
-  double* d_logz_pos = nullptr;   // [nnz]  log z_{i->j} per neighbour position
-  std::vector<double> h_logz_node, h_logz_pos, h_f;
-  EngStats* d_stats = nullptr; int* d_counter = nullptr; wg::Prof* d_prof = nullptr;
-  double* d_one = nullptr; int32_t* d_ones = nullptr; double* d_ident = nullptr; int ident_n = 0;
-  // tables
-  bool tables_dirty = true;
-  double* d_tab = nullptr; size_t tab_doubles = 0;
-  std::vector<int64_t> pxy_off;    // per neighbour position
-  std::vector<int64_t> pxy_tstride;
-  std::vector<int64_t> wmsg_off;   // per neighbour position
-  std::vector<int64_t> wbel_off;   // per node
-  std::vector<int64_t> init_off;   // per node: [ny0][q]
-  std::vector<int64_t> pyy_base;   // per node: offset of prob_yy blob
-  Arena arena, scratch;
-  int num_cu = 256;
-  int profiling = 0;            // 0 off, 1 HIP-event timing of the cavity launches, 2 also the in-kernel phase timers
-  std::string err;
-  mpbp_stats last{};
-
-  int fail(int code, const char* fmt, ...) {
-    char buf[1024];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    err = buf; return code;
-  }
-  int nnz() const { return nbr_ptr[N]; }
-  double* slot_cores(int e) const { return d_cores + (int64_t)slot_of_edge[e] * slot_doubles; }
-  int32_t* slot_bonds(int e) const { return d_bonds + (int64_t)slot_of_edge[e] * (L + 1); }
-};
+thread_local std::string g_create_error;
 
 // ================================================================================================
 // creation / destruction

@@ -1,0 +1,551 @@
+// Grid-level ("batched, lock-step") kernels of the gauge sweep: sweep 1 of the compress engine (engine.h) for problems
+// that one workgroup cannot hold - BASELINE configs[2..4]: product bonds 900 / 1600 / 4096, Y_t up to 16384 x 4096 -
+// and for batches whose workgroup-per-problem form would leave the chip idle.
+//
+// All problems of a batch advance through the time steps together; a time step is a short sequence of launches, each
+// over (problem, tile / row chunk), so that ONE problem can occupy many compute units and a kernel boundary is the only
+// synchronisation (no spin waits).  Per time step t (reference: the orthogonalize_right!(TruncThresh(0.0)) half of
+// compress! inside `op`, src/recursive_bp_factor.jl:127; function-equivalent R-only QR as in engine.h):
+//     k_build_E, k_gemm (Y1: Z = A1 Lf), k_zero_pads, k_gemm (Y2: Y = E Z)            - Y_t = X_t^T
+//     per 64-column block: up to 4 x { k_trailW/k_trailU on the next panel's tile (left-looking inside the block),
+//                                       panel factorisation, k_gram, k_build_T },
+//                          k_trailW / k_trailU<NP> on everything to the right          - blocked Householder QR, R only
+//     k_maxabs, k_lf_write                                                             - Lf_t^T = R / max|R|
+// Panel factorisation: one launch of k_fpanel (register-resident panel, wg::qr_panel_regs) while the rows below the
+// diagonal fit one workgroup (<= 2048), else 17 launches of k_colstep (one Householder column per launch, the rows
+// shared out to chunks of 2048; the per-column dot products are reduced through a small per-problem buffer in a
+// fixed order, so results do not depend on scheduling).
+//
+// Every panel is 16 columns wide: rows [rows, rows32) and columns [cols, cols16 + 16) of Y are zero, a reflector whose
+// column is zero below the diagonal gets tau = 0 and a zero T row/column, and the padding stays zero - so "short" last
+// panels need no special cases anywhere.
+#pragma once
+
+namespace v2 {
+
+using namespace v512::wg;
+
+constexpr int CH = 2048;          // rows per chunk (512 threads x 4 rows for the column steps; 64 stages of 32 rows for the updates)
+
+struct QrProb {
+  double* Y;                      // column-major, ld % 32 == 0; see the padding contract above
+  double* aux;                    // per-problem scratch, AuxLay
+  int32_t ld, rows, cols, kmax;   // kmax = min(rows, cols)
+};
+
+// offsets (doubles) into QrProb::aux - the same for every problem of a batch
+struct AuxLay {
+  int32_t nchunk;                 // partial slots per tile in w0 = nchunk * 4 (row sub-chunks of the in-block updates)
+  int64_t T, S, tau, piv, mx, part, gram, w0;
+};
+__host__ __device__ inline AuxLay make_auxlay(int nchunk, int ntile) {
+  AuxLay a; a.nchunk = nchunk;
+  int64_t o = 0;
+  a.T = o; o += 4 * 256;
+  a.S = o; o += 6 * 256;
+  a.tau = o; o += 64;
+  a.piv = o; o += 256;
+  a.mx = o; o += 16;
+  a.part = o; o += (int64_t)nchunk * 256;
+  a.gram = o; o += (int64_t)nchunk * 4 * 256;
+  a.w0 = o; o += (int64_t)ntile * nchunk * 4 * 4 * 256;
+  (void)o;
+  return a;
+}
+__host__ __device__ inline int64_t auxlay_doubles(int nchunk, int ntile) {
+  return 4 * 256 + 6 * 256 + 64 + 256 + 16 + (int64_t)nchunk * 256 + (int64_t)nchunk * 1024 + (int64_t)ntile * nchunk * 4096;
+}
+
+__device__ __forceinline__ double sel16(const double (&v)[16], int j) {
+  double x = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; c++) x = (c == j) ? v[c] : x;
+  return x;
+}
+
+// Householder reflector of a column with pivot alpha and squared norm ss below it (LAPACK dlarfg; the rsq / rcp +
+// Newton form of wg::qr_panel_step, so that the two panel paths agree to rounding)
+__device__ __forceinline__ void larfg(double alpha, double ss, double& beta, double& tj, double& scale) {
+  if (ss == 0.0) { beta = alpha; tj = 0.0; scale = 0.0; return; }
+  const double n2 = alpha * alpha + ss;
+  double ri = __builtin_amdgcn_rsq(n2);
+  ri = ri * (1.5 - 0.5 * n2 * ri * ri);
+  ri = ri * (1.5 - 0.5 * n2 * ri * ri);
+  double nrm = n2 * ri;
+  nrm = nrm + 0.5 * ri * (n2 - nrm * nrm);
+  beta = -copysign(nrm, alpha);
+  tj = 1.0 + fabs(alpha) * ri;
+  const double dd = alpha - beta;
+  double rd = __builtin_amdgcn_rcp(dd);
+  rd = rd * (2.0 - dd * rd);
+  rd = rd * (2.0 - dd * rd);
+  scale = rd;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Column step jj (0..16) of the panel at column / row jp, rows shared out to chunks of CH.  Launch jj first applies
+// reflector jj-1 (its dot products were left by launch jj-1) and then takes the dot products of column jj.
+// grid (nchunk, nprob), 512 threads.  pidx = index of the panel inside its 64-column block (selects the tau slot).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_colstep(const QrProb* probs, AuxLay lay, int jp, int jj, int pidx) {
+  const QrProb P = probs[blockIdx.y];
+  if (jp >= P.kmax) return;
+  const int chunk = blockIdx.x;
+  const int rows32 = (P.rows + 31) & ~31;
+  const int cfirst = jp / CH, clast = (rows32 - 1) / CH;
+  if (chunk < cfirst || chunk > clast) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  gdbl* Y = (gdbl*)P.Y;
+  gdbl* aux = (gdbl*)P.aux;
+  const long ld = P.ld;
+  __shared__ double red_[8 * 16];
+  ldbl* red = (ldbl*)red_;
+  double Pn[4][16];
+  bool rv[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int r = chunk * CH + tid + 512 * s;
+    rv[s] = r < rows32 && r >= jp;
+    const int rc = rv[s] ? r : jp;
+#pragma unroll
+    for (int c = 0; c < 16; c++) { const double v = Y[(long)(jp + c) * ld + rc]; Pn[s][c] = rv[s] ? v : 0.0; }
+  }
+  if (jj >= 1) {
+    const int j = jj - 1;
+    double tot[16], rowv[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) tot[c] = 0.0;
+    for (int cc = cfirst; cc <= clast; cc++) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) tot[c] += aux[lay.part + ((long)cc * 16 + j) * 16 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) rowv[c] = aux[lay.piv + j * 16 + c];
+    const double ss = sel16(tot, j), alpha = sel16(rowv, j);
+    double beta, tj, scale;
+    larfg(alpha, ss, beta, tj, scale);
+    double tw[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) tw[c] = (c > j) ? tj * (rowv[c] + scale * tot[c]) : 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int r = chunk * CH + tid + 512 * s;
+      const bool below = rv[s] && r > jp + j, pivot = r == jp + j;
+      const double xj = sel16(Pn[s], j);
+      const double v = below ? xj * scale : (pivot ? 1.0 : 0.0);
+      const double nxj = below ? v : (pivot ? beta : xj);
+#pragma unroll
+      for (int c = 0; c < 16; c++) Pn[s][c] = (c == j) ? nxj : Pn[s][c] - tw[c] * v;
+    }
+    if (chunk == cfirst && tid == 0) aux[lay.tau + pidx * 16 + j] = tj;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int r = chunk * CH + tid + 512 * s;
+      if (rv[s]) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) Y[(long)(jp + c) * ld + r] = Pn[s][c];
+      }
+    }
+  }
+  if (jj < 16) {
+    double vals[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) vals[c] = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int r = chunk * CH + tid + 512 * s;
+      const bool below = rv[s] && r > jp + jj;
+      const double x = below ? sel16(Pn[s], jj) : 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; c++) vals[c] += x * Pn[s][c];
+      if (r == jp + jj) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) aux[lay.piv + jj * 16 + c] = Pn[s][c];
+      }
+    }
+    int idx;
+    const double wsum = wave_sum16(vals, lane, idx);
+    if ((lane & 3) == 0) red[wave * 16 + idx] = wsum;
+    __syncthreads();
+    if (tid < 16) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) s += red[w * 16 + tid];
+      aux[lay.part + ((long)chunk * 16 + jj) * 16 + tid] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Register-resident panel (rows below the diagonal <= 2048): the whole 16-column factorisation in ONE launch.
+// grid (nprob), 512 threads.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_fpanel(const QrProb* probs, AuxLay lay, int jp, int pidx) {
+  const QrProb P = probs[blockIdx.x];
+  if (jp >= P.kmax) return;
+  __shared__ double lds_[2 * 8 * 16 + 16 + 64 + 32];
+  ldbl* red = (ldbl*)lds_;
+  ldbl* tau = red + 2 * 8 * 16;
+  ldbl* bc = tau + 16;
+  const int rows32 = (P.rows + 31) & ~31;
+  if (threadIdx.x < 16) tau[threadIdx.x] = 0.0;
+  __syncthreads();
+  qr_panel_regs((gdbl*)P.Y, P.ld, rows32, jp, 16, red, tau, bc);
+  if (threadIdx.x < 16) ((gdbl*)P.aux)[lay.tau + pidx * 16 + threadIdx.x] = tau[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gram blocks of the freshly factored panel x (index pidx of the block at column jb) against itself and the earlier
+// panels of its block:  G_0 = Vx^T Vx,  G_k = Vx^T V_{k-1} (k = 1..pidx), rows of one chunk.  grid (nchunk, nprob).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_gram(const QrProb* probs, AuxLay lay, int jb, int pidx) {
+  const QrProb P = probs[blockIdx.y];
+  const int jx = jb + 16 * pidx;
+  if (jx >= P.kmax) return;
+  const int chunk = blockIdx.x;
+  const int rows32 = (P.rows + 31) & ~31;
+  const int cfirst = jx / CH, clast = (rows32 - 1) / CH;
+  if (chunk < cfirst || chunk > clast) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const gdbl* Y = (const gdbl*)P.Y;
+  gdbl* aux = (gdbl*)P.aux;
+  const long ld = P.ld;
+  const int np = pidx + 1;
+  __shared__ double big_[8 * 1024];
+  ldbl* big = (ldbl*)big_;
+  const int rb0 = max(chunk * CH, jx) >> 4, rb1 = min((chunk + 1) * CH, rows32) >> 4;
+  d4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) acc[k] = d4{0, 0, 0, 0};
+  for (int rb = rb0 + wave; rb < rb1; rb += 8) {
+    const int row0 = 16 * rb + 4 * g;
+    d4 vx = *reinterpret_cast<const gd4*>(Y + (long)(jx + l15) * ld + row0);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rr = row0 + e - jx;
+      double a = vx[e];
+      a = (rr < 16) ? ((rr > l15) ? a : ((rr == l15) ? 1.0 : 0.0)) : a;
+      vx[e] = (rr >= 0) ? a : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (k < np) {
+        const int jy = (k == 0) ? jx : jb + 16 * (k - 1);
+        d4 vy = *reinterpret_cast<const gd4*>(Y + (long)(jy + l15) * ld + row0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int rr = row0 + e - jy;
+          double a = vy[e];
+          a = (rr < 16) ? ((rr > l15) ? a : ((rr == l15) ? 1.0 : 0.0)) : a;
+          vy[e] = (rr >= 0) ? a : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[k] = mfma(vx[e], vy[e], acc[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) big[wave * 1024 + 256 * k + (g + 4 * r) + 16 * l15] = acc[k][r];
+  __syncthreads();
+  for (int idx = tid; idx < 256 * np; idx += 512) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) s += big[w * 1024 + idx];
+    aux[lay.gram + (long)chunk * 1024 + idx] = s;
+  }
+}
+
+// T of the panel from its Gram block and taus, cross Grams S_pr of the block; grid (nprob), 64 threads
+__global__ void __launch_bounds__(64) k_build_T(const QrProb* probs, AuxLay lay, int jb, int pidx) {
+  const QrProb P = probs[blockIdx.x];
+  const int jx = jb + 16 * pidx;
+  if (jx >= P.kmax) return;
+  const int rows32 = (P.rows + 31) & ~31;
+  const int cfirst = jx / CH, clast = (rows32 - 1) / CH;
+  const int tid = threadIdx.x;
+  gdbl* aux = (gdbl*)P.aux;
+  __shared__ double g_[256 + 16 + 256];
+  ldbl* G = (ldbl*)g_;
+  ldbl* tau = G + 256;
+  ldbl* Ts = tau + 16;
+  const int np = pidx + 1;
+  for (int k = 0; k < np; k++) {
+    for (int idx = tid; idx < 256; idx += 64) {
+      double s = 0.0;
+      for (int cc = cfirst; cc <= clast; cc++) s += aux[lay.gram + (long)cc * 1024 + 256 * k + idx];
+      if (k == 0) G[idx] = s;
+      else aux[lay.S + (long)(pidx * (pidx - 1) / 2 + (k - 1)) * 256 + idx] = s;
+    }
+  }
+  if (tid < 16) tau[tid] = aux[lay.tau + pidx * 16 + tid];
+  __syncthreads();
+  qr_T_from_gram(G, tau, 16, Ts);
+  for (int idx = tid; idx < 256; idx += 64) aux[lay.T + pidx * 256 + idx] = Ts[idx];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Block-reflector update of 16-column tiles by the NP panels of the block at column jb:
+//     C <- C - sum_p V_p W_p,   W_p = T_p^T (V_p^T C - sum_{r<p} S_pr W_r)
+// in two launches: k_trailW leaves the partial products V_p^T C of every (tile, row sub-chunk), k_trailU sums them
+// in a fixed order, runs the W recurrence and updates its own rows.
+// A workgroup of 4 waves covers tw tiles x rw row sub-chunks (tw * rw = 4): tw = 4 for the trailing matrix, rw = 4 for
+// the single tile of a left-looking update inside the block.  grid (ceil(ntile / tw), nchunk, nprob), 256 threads.
+// `inblock`: the tile is panel NP of the block (column jb + 16 NP); else tiles start right of the block's panels.
+// ------------------------------------------------------------------------------------------------------------------
+struct TrailGeom { int np, c0, ntile; };
+__device__ __forceinline__ TrailGeom trail_geom(const QrProb& P, int jb, int NP, bool inblock) {
+  TrailGeom G;
+  const int npan = (P.kmax - jb + 15) >> 4;              // panels of this problem from column jb on (>= 1)
+  if (inblock) { G.np = NP; G.c0 = jb + 16 * NP; G.ntile = (npan > NP) ? 1 : 0; return G; }
+  G.np = min(NP, npan);                                  // NP = panels of the widest problem in this block (<= 4)
+  G.c0 = jb + 16 * G.np;
+  G.ntile = (P.cols > G.c0) ? (P.cols - G.c0 + 15) >> 4 : 0;
+  return G;
+}
+
+template <int NP>
+__global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw) {
+  const QrProb P = probs[blockIdx.z];
+  if (jb >= P.kmax) return;
+  const TrailGeom G = trail_geom(P, jb, NP, inblock != 0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int rw = 4 / tw;
+  const int tile = blockIdx.x * tw + (wave % tw), rsub = wave / tw;
+  if (tile >= G.ntile) return;
+  const int rows32 = (P.rows + 31) & ~31;
+  const int chunk = blockIdx.y;
+  const int sub = CH / rw;                                 // rows per sub-chunk (multiple of 32)
+  const int ra = max(chunk * CH + rsub * sub, jb), rbnd = min(chunk * CH + (rsub + 1) * sub, rows32);
+  const gdbl* Y = (const gdbl*)P.Y;
+  gdbl* aux = (gdbl*)P.aux;
+  const long ld = P.ld;
+  const int cb0 = G.c0 + 16 * tile;
+  d4 acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) acc[p] = d4{0, 0, 0, 0};
+  const gdbl* ccol = Y + (long)(cb0 + l15) * ld + 4 * g;
+  for (int rb = ra >> 4; rb < (rbnd >> 4); rb++) {
+    const int row0 = 16 * rb + 4 * g;
+    const d4 c = *reinterpret_cast<const gd4*>(ccol + 16 * rb);
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      if (p < G.np) {
+        const int jv = jb + 16 * p;
+        d4 v = *reinterpret_cast<const gd4*>(Y + (long)(jv + l15) * ld + row0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int rr = row0 + e - jv;
+          double a = v[e];
+          a = (rr < 16) ? ((rr > l15) ? a : ((rr == l15) ? 1.0 : 0.0)) : a;
+          v[e] = (rr >= 0) ? a : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[p] = mfma(v[e], c[e], acc[p]);
+      }
+    }
+  }
+  gdbl* w0 = aux + lay.w0 + ((long)tile * (lay.nchunk * 4) + chunk * 4 + rsub) * 1024;
+#pragma unroll
+  for (int p = 0; p < NP; p++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) w0[256 * p + (g + 4 * r) + 16 * l15] = acc[p][r];
+}
+
+template <int NP>
+__global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw) {
+  const QrProb P = probs[blockIdx.z];
+  if (jb >= P.kmax) return;
+  const TrailGeom G = trail_geom(P, jb, NP, inblock != 0);
+  if (G.ntile == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  gdbl* Y = (gdbl*)P.Y;
+  const gdbl* aux = (const gdbl*)P.aux;
+  const long ld = P.ld;
+  __shared__ double ts_[10 * 256];
+  ldbl* Tq = (ldbl*)ts_;
+  ldbl* Sq = Tq + 4 * 256;
+  for (int i = tid; i < 4 * 256; i += 256) Tq[i] = aux[lay.T + i];
+  for (int i = tid; i < 6 * 256; i += 256) Sq[i] = aux[lay.S + i];
+  __syncthreads();
+  const int rw = 4 / tw;
+  const int tile = blockIdx.x * tw + (wave % tw), rsub = wave / tw;
+  if (tile >= G.ntile) return;
+  const int rows32 = (P.rows + 31) & ~31;
+  const int chunk = blockIdx.y;
+  const int sub = CH / rw;
+  const int ra = max(chunk * CH + rsub * sub, jb & ~31), rbnd = min(chunk * CH + (rsub + 1) * sub, rows32);
+  if (ra >= rbnd) return;
+  const int cb0 = G.c0 + 16 * tile;
+  // partial products of every slot that took part: chunks from the one holding row jb, all 4 / rw... sub-chunks
+  const int cfirst = jb / CH, clast = (rows32 - 1) / CH;
+  d4 w[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    d4 t = d4{0, 0, 0, 0};
+    if (p < G.np) {
+      for (int cc = cfirst; cc <= clast; cc++)
+        for (int rs = 0; rs < rw; rs++) {
+          // sub-chunks entirely above row jb or below the matrix wrote nothing: skip them exactly as k_trailW did
+          const int sa = max(cc * CH + rs * sub, jb), sb = min(cc * CH + (rs + 1) * sub, rows32);
+          if ((sa >> 4) >= (sb >> 4)) continue;
+          const gdbl* w0 = aux + lay.w0 + ((long)tile * (lay.nchunk * 4) + cc * 4 + rs) * 1024 + 256 * p;
+#pragma unroll
+          for (int r = 0; r < 4; r++) t[r] += w0[(g + 4 * r) + 16 * l15];
+        }
+#pragma unroll
+      for (int r = 0; r < NP; r++) {
+        if (r < p) {
+          const ldbl* S = Sq + (p * (p - 1) / 2 + r) * 256;
+#pragma unroll
+          for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][s], t);
+        }
+      }
+      d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) o = mfma(Tq[p * 256 + (4 * s + g) + 16 * l15], t[s], o);
+      t = o;
+    }
+    w[p] = t;
+  }
+  for (int st = ra >> 5; st < (rbnd >> 5); st++) {
+    const int row = 32 * st + 2 * l15;
+    d2 v[NP][4];
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        const int k = 4 * s2 + g;
+        d2 x = d2{0, 0};
+        if (p < G.np) {
+          x = *reinterpret_cast<const gd2*>(Y + (long)(jb + 16 * p + k) * ld + row);
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const int rp = row + e - jb - 16 * p;
+            double a = x[e];
+            a = (rp < 16) ? ((rp > k) ? a : ((rp == k) ? 1.0 : 0.0)) : a;
+            x[e] = (rp >= 0) ? a : 0.0;
+          }
+        }
+        v[p][s2] = x;
+      }
+    d2 c[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      d4 a4 = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+        for (int p = 0; p < NP; p++) a4 = mfma(-w[p][s2], v[p][s2][e], a4);
+#pragma unroll
+      for (int r = 0; r < 4; r++) c[r][e] = a4[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) *reinterpret_cast<gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row) = c[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Batched contraction O = S X with separable two-level index maps (the Y1 / Y2 assembly of engine.h, every wave of
+// the grid taking 16-column tiles of the output).  grid (nwg, ngemm), 512 threads.
+// ------------------------------------------------------------------------------------------------------------------
+struct Map2 {
+  int32_t d; int64_t s0, s1;                       // f(i) = (i % d) * s0 + (i / d) * s1
+  __device__ __forceinline__ long operator()(int i) const { return (long)(i % d) * s0 + (long)(i / d) * s1; }
+};
+struct GemmDesc {
+  const double* S; const double* X; double* O;
+  int32_t M, N, K, pad;
+  Map2 sro, sco, xro, xco, oro, oco;
+};
+__global__ void __launch_bounds__(512) k_gemm(const GemmDesc* descs) {
+  const GemmDesc D = descs[blockIdx.y];
+  if (D.M <= 0 || D.N <= 0) return;
+  const int wave = threadIdx.x >> 6;
+  const int tile0 = blockIdx.x * 8 + wave, tstride = gridDim.x * 8;
+  if (blockIdx.x * 8 * 16 >= D.N) return;           // whole workgroup beyond the last tile
+  gemm_direct<false, false>(D.M, D.N, D.K, (const gdbl*)D.S, D.sro, D.sco, (const gdbl*)D.X, D.xro, D.xco, (gdbl*)D.O,
+                            D.oro, D.oco, false, tile0, tstride);
+}
+
+// E_xi[(m2 + b*y) + M2*(n2 + bn*y1)] = sum_y2 pyy[y,y1,y2,xi] A2[m2,n2,y2,xi]   (engine.h build_E); grid (nwg, nprob)
+struct EDesc {
+  const double* A2; const double* pyy; double* E;
+  int32_t b, bn, ny, ny1, ny2, q;
+};
+__global__ void __launch_bounds__(256) k_build_E(const EDesc* descs) {
+  const EDesc D = descs[blockIdx.y];
+  const int M2 = D.b * D.ny, K2 = D.bn * D.ny1;
+  const long tot = (long)M2 * K2 * D.q;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % M2); const long rest = idx / M2; const int kk = (int)(rest % K2); const int xi = (int)(rest / K2);
+    const int m2 = i % D.b, y = i / D.b, n2 = kk % D.bn, y1 = kk / D.bn;
+    double s = 0.0;
+    for (int y2 = 0; y2 < D.ny2; y2++) {
+      const double c = D.pyy[y + D.ny * (y1 + D.ny1 * (y2 + D.ny2 * xi))];
+      if (c != 0.0) s += c * D.A2[m2 + (long)D.b * (n2 + (long)D.bn * (y2 + D.ny2 * xi))];
+    }
+    D.E[idx] = s;
+  }
+}
+
+// zero the padding of Y for this step (rows [rows, rows32) of columns [0, cols), columns [cols, cols16 + 16) over rows32)
+// and the max-abs slot; grid (nwg, nprob), 256 threads
+__global__ void __launch_bounds__(256) k_zero_pads(const QrProb* probs, AuxLay lay) {
+  const QrProb P = probs[blockIdx.y];
+  gdbl* Y = (gdbl*)P.Y;
+  const long ld = P.ld;
+  const int rows32 = (P.rows + 31) & ~31, cols16 = ((P.cols + 15) & ~15) + 16;
+  const int padr = rows32 - P.rows;
+  const long gtid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)gridDim.x * 256;
+  if (gtid == 0) *(unsigned long long*)(P.aux + lay.mx) = 0ULL;
+  if (padr > 0)
+    for (long idx = gtid; idx < (long)padr * P.cols; idx += gsz) Y[(long)(idx / padr) * ld + P.rows + (idx % padr)] = 0.0;
+  const long nz = (long)rows32 * (cols16 - P.cols);
+  for (long idx = gtid; idx < nz; idx += gsz) Y[(long)(P.cols + idx / rows32) * ld + (idx % rows32)] = 0.0;
+}
+
+// max |R| over the upper trapezoid; grid (nwg, nprob), 256 threads
+__global__ void __launch_bounds__(256) k_maxabs(const QrProb* probs, AuxLay lay) {
+  const QrProb P = probs[blockIdx.y];
+  const gdbl* Y = (const gdbl*)P.Y;
+  const long ld = P.ld;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  double mx = 0.0;
+  for (int m = gw; m < P.cols; m += nw) {
+    const int kend = min(P.kmax, m + 1);
+    for (int k = lane; k < kend; k += 64) mx = fmax(mx, fabs(Y[(long)m * ld + k]));
+  }
+  mx = wave_max(mx);
+  if (lane == 0 && mx > 0.0) atomicMax((unsigned long long*)(P.aux + lay.mx), (unsigned long long)__double_as_longlong(mx));
+}
+
+// Lf_t^T = R / max|R|  as [kmax x cols], ld kmax (rank index fastest); grid (nwg, nprob), 256 threads
+struct LfDesc { double* Lf; };
+__global__ void __launch_bounds__(256) k_lf_write(const QrProb* probs, const LfDesc* lfd, AuxLay lay) {
+  const QrProb P = probs[blockIdx.y];
+  const gdbl* Y = (const gdbl*)P.Y;
+  gdbl* Lf = (gdbl*)lfd[blockIdx.y].Lf;
+  const long ld = P.ld;
+  const double mx = P.aux[lay.mx];
+  const double inv = (mx > 0.0 && isfinite(mx)) ? 1.0 / mx : 1.0;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  const int kmax = P.kmax;
+  for (int m = gw; m < P.cols; m += nw) {
+    const gdbl* yc = Y + (long)m * ld;
+    gdbl* lc = Lf + (long)kmax * m;
+    const int kend = min(kmax, m + 1);
+    for (int k = lane; k < kend; k += 64) lc[k] = yc[k] * inv;
+    for (int k = kend + lane; k < kmax; k += 64) lc[k] = 0.0;
+  }
+}
+
+}  // namespace v2

@@ -30,7 +30,7 @@ template <bool NTX = false, bool NTO = false, class SP, class XP, class OP, clas
           class ORO, class OCO>
 __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp, SRO sro, SCO sco,
                                                      XP Xp, XRO xro, XCO xco, OP Op, ORO oro, OCO oco,
-                                                     bool accumulate);
+                                                     bool accumulate, int tile0 = -1, int tstride = WG_WAVES);
 
 // O(i,j) (+)= sum_k S(i,k) X(k,j),  i<M, j<N, k<K.
 //   S(i,k) = Sp[sro(i) + sco(k)],  X(k,j) = Xp[xro(k) + xco(j)],  O(i,j) = Op[oro(i) + oco(j)].
@@ -178,7 +178,9 @@ __device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* 
 template <bool NTX, bool NTO, class SP, class XP, class OP, class SRO, class SCO, class XRO, class XCO, class ORO, class OCO>
 __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp, SRO sro, SCO sco,
                                                      XP Xp, XRO xro, XCO xco, OP Op, ORO oro, OCO oco,
-                                                     bool accumulate) {
+                                                     bool accumulate, int tile0, int tstride) {
+  // tile0 / tstride: first 16-column output tile of this wave and the stride to its next one (defaults: the waves of
+  // ONE workgroup share the tiles; the grid-level contractions of the batched sweep pass global wave numbers)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
@@ -211,7 +213,7 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
         G.kin |= kin ? (1u << u) : 0u;
       }
     };
-    int tl = wave;
+    int tl = tile0 < 0 ? wave : tile0;
     if (tl < ntile) {
       int j = tl * 16 + l15;
       bool jin = j < N;
@@ -222,7 +224,7 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
         d4 acc[6];
 #pragma unroll
         for (int t = 0; t < 6; t++) acc[t] = d4{0, 0, 0, 0};
-        const int tl2 = tl + WG_WAVES;
+        const int tl2 = tl + tstride;
         const int j2 = tl2 * 16 + l15;
         const bool jin2 = j2 < N;
         long cofs2 = 0;

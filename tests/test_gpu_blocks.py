@@ -83,3 +83,50 @@ def test_qr_small_and_degenerate_shapes(variant):
         assert rc == 0 and np.isfinite(R).all(), (r, c)
         G1, G2 = R.T @ R, A.T @ A
         assert np.abs(G1 - G2).max() <= 1e-12 * max(np.abs(G2).max(), 1e-300), (r, c, variant)
+
+
+def _qr_batched(A3, force_tall):
+    """A3: [nprob, rows, cols] -> R [nprob, kmax, cols] through the grid-level batched QR (v2_kernels.h)."""
+    nprob, rows, cols = A3.shape
+    k = min(rows, cols)
+    Af = np.concatenate([np.asfortranarray(A3[p]).ravel(order="F") for p in range(nprob)])
+    R = np.zeros(nprob * k * cols)
+    ms = C.c_double(0.0)
+    rc = mpbp_amd._lib.lib().mpbp_selftest_qr_batched(0, rows, cols, nprob, int(force_tall), _dp(Af), _dp(R), C.byref(ms))
+    assert rc == 0
+    return np.stack([R[p * k * cols:(p + 1) * k * cols].reshape((k, cols), order="F") for p in range(nprob)]), ms.value
+
+
+@pytest.mark.parametrize("force_tall", [0, 1])
+def test_qr_batched_shapes(force_tall):
+    """Grid-level QR of the batched gauge sweep: register-panel path and column-step ("tall") path over the shapes of the
+    first sweeps (bonds 1, 4, 16), wide / square / tall matrices, rank-deficient and badly scaled inputs."""
+    rng = np.random.default_rng(21)
+    shapes = [(1, 1), (1, 4), (2, 8), (4, 16), (4, 20), (4, 64), (8, 4), (12, 40), (16, 64), (20, 17), (40, 20), (64, 64),
+              (80, 40), (100, 33), (128, 200), (160, 40), (320, 80), (400, 80), (640, 100), (1000, 130), (1600, 400)]
+    for (r, c) in shapes:
+        for variant in ("random", "duplicate_column", "tiny_columns"):
+            A = rng.standard_normal((3, r, c))
+            if variant == "duplicate_column" and c > 2:
+                A[:, :, 1] = A[:, :, 0]
+            if variant == "tiny_columns":
+                A[:, :, c // 2:] *= 1e-150
+            R, _ = _qr_batched(A, force_tall)
+            assert np.isfinite(R).all(), (r, c, variant)
+            for p in range(3):
+                G1, G2 = R[p].T @ R[p], A[p].T @ A[p]
+                assert np.abs(G1 - G2).max() <= 1e-12 * max(np.abs(G2).max(), 1e-300), (r, c, variant, p)
+
+
+@pytest.mark.parametrize("rows,cols", [(2100, 96), (4500, 160), (6400, 400), (3000, 900)])
+def test_qr_batched_tall(rows, cols):
+    """Rows beyond one workgroup's register panel (BASELINE configs[2..4] shapes, reduced): column-step panels over
+    several row chunks, multi-chunk block-reflector updates."""
+    rng = np.random.default_rng(22)
+    A = rng.standard_normal((2, rows, cols)) * np.logspace(0, -12, cols)[None, None, :]
+    R, _ = _qr_batched(A, 0)
+    for p in range(2):
+        Rn = np.linalg.qr(A[p], mode="r")
+        sgn = np.sign(np.diag(Rn)) * np.sign(np.diag(R[p]))
+        sgn[sgn == 0] = 1
+        assert np.abs(R[p] * sgn[:, None] - Rn).max() < 1e-11 * np.abs(Rn).max()
