@@ -77,7 +77,7 @@ struct mpbp_ctx {
   std::vector<int64_t> wbel_off;   // per node
   std::vector<int64_t> init_off;   // per node: [ny0][q]
   std::vector<int64_t> pyy_base;   // per node: offset of prob_yy blob
-  Arena arena, scratch;
+  Arena arena, scratch, v2arena;   // work trains of a sweep / engine slots + launch records / batched gauge sweep
   int num_cu = 256;
   int profiling = 0;            // 0 off, 1 HIP-event timing of the cavity launches, 2 also the in-kernel phase timers
   std::string err;
@@ -92,3 +92,18 @@ struct mpbp_ctx {
   double* slot_cores(int e) const { return d_cores + (int64_t)slot_of_edge[e] * slot_doubles; }
   int32_t* slot_bonds(int e) const { return d_bonds + (int64_t)slot_of_edge[e] * (L + 1); }
 };
+
+// grows an arena (contents are NOT preserved); used between launches only
+inline int ensure_arena(mpbp_ctx* c, Arena& a, size_t bytes) {
+  if (a.cap >= bytes) return MPBP_OK;
+  if (a.base) { hipFree(a.base); a.base = nullptr; a.cap = 0; }
+  size_t want = bytes + (bytes >> 3) + (1 << 20);
+  hipError_t e = hipMalloc((void**)&a.base, want);
+  if (e != hipSuccess) {
+    want = bytes + 4096;
+    e = hipMalloc((void**)&a.base, want);
+  }
+  if (e != hipSuccess) return c->fail(MPBP_ENOMEM, "hipMalloc(%zu MiB work arena) failed: %s", want >> 20, hipGetErrorString(e));
+  a.cap = want;
+  return MPBP_OK;
+}

@@ -105,14 +105,21 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
   auto LB1 = [&](int t) { return mirror ? Pb1[L - t] : Pb1[t]; };
   auto LB2 = [&](int t) { return mirror ? Pb2[L - t] : Pb2[t]; };
   auto TP = [&](int t) { return mirror ? (L - 1 - t) : t; };
+  // triangular factors: own sweep 1 (slot stack, ranks in LDS) or the batched gauge sweep's (P.lf != null)
+  const bool ext = P.lf != nullptr;
+  const gdbl* Plf = (const gdbl*)P.lf;
+  const __attribute__((address_space(1))) int64_t* Plfoff = (const __attribute__((address_space(1))) int64_t*)P.lfoff;
+  const gint* Prd = (const gint*)P.rdim;
+  auto RD = [&](int t) -> int { return ext ? (int)Prd[t] : (int)rdim[t]; };
+  auto LFP = [&](int t) -> const gdbl* { return ext ? Plf + Plfoff[t] : (const gdbl*)(LfS + (int64_t)t * cfg.lf_stride); };
   Prof* pr = cfg.prof;
   unsigned long long plast = pr ? wall_clock64() : 0ULL;
 #define PROF(ph) prof_mark(pr, plast, ph)
 
   // ------------------------------------------------------------------ sweep 1: triangular factors
-  if (tid == 0) { rdim[L] = 1; LfS[(int64_t)L * cfg.lf_stride] = 1.0; }
+  if (tid == 0 && !ext) { rdim[L] = 1; LfS[(int64_t)L * cfg.lf_stride] = 1.0; }
   __syncthreads();
-  for (int t = L - 1; t >= 1; t--) {
+  for (int t = ext ? 0 : L - 1; t >= 1; t--) {
     const int a = LB1(t), an = LB1(t + 1), b = LB2(t), bn = LB2(t + 1);
     const int Bm = a * b, Bn = an * bn;
     const int r1 = rdim[t + 1];
@@ -242,8 +249,8 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
       __syncthreads();
       break;
     }
-    const int r1 = rdim[t + 1];
-    const gdbl* Lf1 = LfS + (int64_t)(t + 1) * cfg.lf_stride;
+    const int r1 = RD(t + 1);
+    const gdbl* Lf1 = LFP(t + 1);
     // Mt^T [r1 x Rr] = Lf1^T Nt^T
     const int ldM = r32(r1);
     const int Rr16 = r16(Rr) + 16;

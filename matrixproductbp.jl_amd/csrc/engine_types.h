@@ -11,6 +11,9 @@ struct EngProb {
   const double* pyy; int64_t pyy_tstride;   // pyy[tp*tstride + y + ny*(y1 + ny1*(y2 + ny2*xi))]
   int32_t ny, q, mirror, cap_out;
   double* out; int32_t* obond; int64_t ostride; double* ologz;            // output cores [m,n,y,xi]
+  // triangular factors of sweep 1 supplied by the batched gauge sweep (v2_engine.hip): Lf_t^T at lf + lfoff[t] as
+  // [rdim[t] x a_t b_t], ld rdim[t]; null = the workgroup runs sweep 1 itself into its slot
+  const double* lf; const int64_t* lfoff; const int32_t* rdim;
 };
 
 struct EngCfg {

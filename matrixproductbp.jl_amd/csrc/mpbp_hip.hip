@@ -4,6 +4,7 @@
 // (src/recursive_bp_factor.jl:140), lay trains out in HBM and launch the kernels of kernels.h.
 #include "kernels.h"
 #include "ctx.h"
+#include "v2_engine.h"
 
 thread_local std::string g_create_error;
 
@@ -101,7 +102,7 @@ extern "C" void mpbp_destroy(mpbp_ctx* c) {
   if (c->own_cores && c->d_cores) hipFree(c->d_cores);
   if (c->own_bonds && c->d_bonds) hipFree(c->d_bonds);
   for (void* p : {(void*)c->d_beliefs, (void*)c->d_logz_node, (void*)c->d_logz_pos, (void*)c->d_stats, (void*)c->d_counter, (void*)c->d_prof, (void*)c->d_btrain, (void*)c->d_bbond,
-                  (void*)c->d_one, (void*)c->d_ones, (void*)c->d_ident, (void*)c->d_tab, (void*)c->arena.base, (void*)c->scratch.base})
+                  (void*)c->d_one, (void*)c->d_ones, (void*)c->d_ident, (void*)c->d_tab, (void*)c->arena.base, (void*)c->scratch.base, (void*)c->v2arena.base})
     if (p) hipFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -357,20 +358,11 @@ struct EventPair {
   EventPair& operator=(const EventPair&) = delete;
 };
 
-static int ensure_arena(mpbp_ctx* c, Arena& a, size_t bytes) {
-  if (a.cap >= bytes) return MPBP_OK;
-  if (a.base) { hipFree(a.base); a.base = nullptr; a.cap = 0; }
-  size_t want = bytes + (bytes >> 3) + (1 << 20);
-  hipError_t e = hipMalloc((void**)&a.base, want);
-  if (e != hipSuccess) return c->fail(MPBP_ENOMEM, "hipMalloc(%zu MiB work arena) failed: %s", want >> 20, hipGetErrorString(e));
-  a.cap = want;
-  return MPBP_OK;
-}
-
 struct EngLaunchPlan {
   std::vector<EngProb> probs; std::vector<double> cost;
   int cap1 = 1, cap2 = 1, ny1 = 1, ny2 = 1, ny = 1, q = 1, capout = 1;
   bool small = false;       // run on the single-wave engine variant (v64)
+  bool ext = false;         // sweep 1 done by the batched gauge sweep: no Lf stack / Z / Y in the slots
 };
 
 // A problem goes to the single-wave engine when every QR panel of its first sweep fits the register panel of
@@ -392,10 +384,13 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   cfg.Bmax = (int)Bmax; cfg.nmax = nmax;
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off += (n + 15) & ~int64_t(15); return o; };
-  cfg.lf_stride = (Bmax * Bmax + 15) & ~int64_t(15);
-  cfg.off_Lf = take(cfg.lf_stride * (L + 1));
-  cfg.off_Z = take((int64_t)pl.cap1 * pl.ny1 * pl.q * pl.cap2 * Bmax);
-  cfg.off_Y = take((int64_t)(r16h((int)(Bmax * pl.ny * pl.q)) + 32) * (r16h((int)Bmax) + 16));
+  if (pl.ext) { cfg.lf_stride = 16; cfg.off_Lf = take(16); cfg.off_Z = take(16); cfg.off_Y = take(16); }
+  else {
+    cfg.lf_stride = (Bmax * Bmax + 15) & ~int64_t(15);
+    cfg.off_Lf = take(cfg.lf_stride * (L + 1));
+    cfg.off_Z = take((int64_t)pl.cap1 * pl.ny1 * pl.q * pl.cap2 * Bmax);
+    cfg.off_Y = take((int64_t)(r16h((int)(Bmax * pl.ny * pl.q)) + 32) * (r16h((int)Bmax) + 16));
+  }
   cfg.off_C0 = take((int64_t)pl.capout * Bmax);
   cfg.off_C1 = take((int64_t)pl.capout * Bmax);
   cfg.off_T1 = take((int64_t)pl.cap1 * pl.ny1 * pl.q * pl.capout * pl.cap2);
@@ -452,39 +447,70 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   // sooner, a single wave per problem only pays off when there are enough problems to fill 4 of them per CU
   // (MPBP_DEBUG_FORCE_SMALL=1 keeps them on the single-wave engine so that small tests cover it)
   if (pl.small && nprob <= 2 * c->num_cu && !getenv("MPBP_DEBUG_FORCE_SMALL")) pl.small = false;
-  EngCfg cfg; size_t lds_bytes;
-  plan_cfg(pl, c->L, trunc, cfg, lds_bytes);
-  // phase timers cover the 512-thread cavity launches; MPBP_PROF_SMALL=1 covers the single-wave launches instead
-  static const bool prof_small = [] { const char* e = getenv("MPBP_PROF_SMALL"); return e && e[0] == '1'; }();
-  cfg.prof = (c->profiling >= 2 && (prof_small ? pl.small : count_as_orth)) ? c->d_prof : nullptr;
-  const void* kern = pl.small ? (const void*)v64::eng_kernel : (const void*)v512::eng_kernel;
-  const int nthreads = pl.small ? 64 : 512;
-  HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  int per_cu = 1;
-  if (pl.small) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v64::eng_kernel, nthreads, lds_bytes);
-  else hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v512::eng_kernel, nthreads, lds_bytes);
-  if (per_cu < 1) per_cu = 1;
-  int nslots = std::min(nprob, c->num_cu * per_cu);
-  // scratch: bounded by a budget; fewer slots if needed
-  size_t slot_bytes = (size_t)cfg.slot_doubles * 8;
-  size_t freeb = 0, totb = 0;
-  hipMemGetInfo(&freeb, &totb);
-  size_t budget = c->scratch.cap + (size_t)(freeb * 0.85);
-  while (nslots > 1 && (size_t)nslots * slot_bytes > budget) nslots = (nslots + 1) / 2;
-  int rc = ensure_arena(c, c->scratch, (size_t)nslots * slot_bytes + sizeof(EngProb) * nprob + 4096);
-  if (rc != MPBP_OK) return rc;
-  double* d_scr = (double*)c->scratch.base;
-  EngProb* d_probs = (EngProb*)(c->scratch.base + (((size_t)nslots * slot_bytes + 255) & ~size_t(255)));
-  HIPCHK(c, hipMemcpyAsync(d_probs, sorted.data(), sizeof(EngProb) * nprob, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream));
+  // Where sweep 1 runs: in the problem's own workgroup (slot-resident Lf stack), or as the batched, grid-level gauge
+  // sweep of v2_engine.hip.  MPBP_GAUGE=grid|wg forces one; otherwise the grid form is taken when a workgroup cannot
+  // hold the problem (Y_t beyond one register panel's rows) or its slot would be huge.
+  bool grid = false;
+  if (!pl.small) {
+    const int64_t Bm = (int64_t)pl.cap1 * pl.cap2;
+    const char* gm = getenv("MPBP_GAUGE");
+    if (gm && !strcmp(gm, "grid")) grid = true;
+    else if (gm && !strcmp(gm, "wg")) grid = false;
+    else grid = Bm * pl.ny * pl.q > 2048 || Bm * Bm * (c->L + 1) * 8 > (int64_t)256 << 20;
+    for (const EngProb& P : sorted) if (P.mirror) grid = false;
+  }
+  pl.ext = grid;
+  auto run = [&](EngProb* ps, int np) -> int {
+    EngCfg cfg; size_t lds_bytes;
+    plan_cfg(pl, c->L, trunc, cfg, lds_bytes);
+    // phase timers cover the 512-thread cavity launches; MPBP_PROF_SMALL=1 covers the single-wave launches instead
+    static const bool prof_small = [] { const char* e = getenv("MPBP_PROF_SMALL"); return e && e[0] == '1'; }();
+    cfg.prof = (c->profiling >= 2 && (prof_small ? pl.small : count_as_orth)) ? c->d_prof : nullptr;
+    const void* kern = pl.small ? (const void*)v64::eng_kernel : (const void*)v512::eng_kernel;
+    const int nthreads = pl.small ? 64 : 512;
+    HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int per_cu = 1;
+    if (pl.small) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v64::eng_kernel, nthreads, lds_bytes);
+    else hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v512::eng_kernel, nthreads, lds_bytes);
+    if (per_cu < 1) per_cu = 1;
+    int nslots = std::min(np, c->num_cu * per_cu);
+    // scratch: bounded by a budget; fewer slots if needed
+    size_t slot_bytes = (size_t)cfg.slot_doubles * 8;
+    size_t freeb = 0, totb = 0;
+    hipMemGetInfo(&freeb, &totb);
+    size_t budget = c->scratch.cap + (size_t)(freeb * 0.85);
+    while (nslots > 1 && (size_t)nslots * slot_bytes > budget) nslots = (nslots + 1) / 2;
+    int rc = ensure_arena(c, c->scratch, (size_t)nslots * slot_bytes + sizeof(EngProb) * np + 4096);
+    if (rc != MPBP_OK) return rc;
+    double* d_scr = (double*)c->scratch.base;
+    EngProb* d_probs = (EngProb*)(c->scratch.base + (((size_t)nslots * slot_bytes + 255) & ~size_t(255)));
+    HIPCHK(c, hipMemcpyAsync(d_probs, ps, sizeof(EngProb) * np, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream));
+    if (pl.small) hipLaunchKernelGGL(v64::eng_kernel, dim3(nslots), dim3(64), lds_bytes, c->stream, d_probs, np, c->d_counter, cfg, d_scr, c->d_stats);
+    else hipLaunchKernelGGL(v512::eng_kernel, dim3(nslots), dim3(512), lds_bytes, c->stream, d_probs, np, c->d_counter, cfg, d_scr, c->d_stats);
+    (void)kern;
+    HIPCHK(c, hipGetLastError());
+    return MPBP_OK;
+  };
   const bool timed = count_as_orth && c->profiling;
   EventPair lev;
   hipEvent_t e0 = timed ? lev.a : nullptr, e1 = lev.b;
   if (timed) hipEventRecord(e0, c->stream);
-  if (pl.small) hipLaunchKernelGGL(v64::eng_kernel, dim3(nslots), dim3(64), lds_bytes, c->stream, d_probs, nprob, c->d_counter, cfg, d_scr, c->d_stats);
-  else hipLaunchKernelGGL(v512::eng_kernel, dim3(nslots), dim3(512), lds_bytes, c->stream, d_probs, nprob, c->d_counter, cfg, d_scr, c->d_stats);
-  (void)kern;
-  HIPCHK(c, hipGetLastError());
+  if (!grid) {
+    int rc = run(sorted.data(), nprob);
+    if (rc != MPBP_OK) return rc;
+  } else {
+    for (int done = 0; done < nprob;) {
+      int nd = 0;
+      int rc = v2_gauge_sweep(c, sorted.data() + done, nprob - done, &nd);
+      if (rc != MPBP_OK) return rc;
+      rc = run(sorted.data() + done, nd);
+      if (rc != MPBP_OK) return rc;
+      // the triangular factors live in c->v2arena until sweep 2 has consumed them
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      done += nd;
+    }
+  }
   if (e0) {
     hipEventRecord(e1, c->stream); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_orth += ms; *n_orth += 1;

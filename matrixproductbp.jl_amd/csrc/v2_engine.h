@@ -2,3 +2,9 @@
 // driver / workgroup-per-problem engine (mpbp_hip.hip).
 #pragma once
 #include "ctx.h"
+
+// Sweep 1 (triangular factors Lf_t of the product trains) of probs[0 .. n) as one lock-step batch of grid-level
+// launches on c->stream.  Processes the longest prefix whose buffers fit device memory (*n_done, >= 1 on success) and
+// sets probs[i].lf / lfoff / rdim (pointers into c->v2arena, valid until the next call).  Problems must not be
+// mirrored.  Asynchronous: the caller may enqueue sweep 2 on the same stream right away.
+int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, int* n_done);

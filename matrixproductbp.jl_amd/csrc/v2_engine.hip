@@ -124,3 +124,192 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
   hipFree(dY); hipFree(dAux); hipFree(dP);
   return MPBP_OK;
 }
+
+// ================================================================================================
+// the batched gauge sweep
+// ================================================================================================
+namespace {
+
+struct StepDims { int a, an, b, bn, r1, rows, cols, kmax; };
+
+struct ProbPlan {
+  std::vector<StepDims> st;        // [L]; entries 1 .. L-1 used
+  std::vector<int64_t> lfoff;      // [L+1]
+  std::vector<int32_t> rdim;       // [L+1]
+  int64_t lf_doubles = 0, y_doubles = 0, z_doubles = 0, e_doubles = 0;
+  int rows32_max = 0, cols_max = 0;
+};
+
+inline v2::Map2 lin(int64_t s) { return v2::Map2{1 << 30, s, 0}; }
+
+}  // namespace
+
+int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, int* n_done) {
+  *n_done = 0;
+  if (n <= 0) return MPBP_OK;
+  const int L = c->L;
+  hipStream_t st = c->stream;
+  // ---- bond tables of the operands (produced on the device by earlier launches) -> host
+  std::vector<int32_t> hb((size_t)n * 2 * (L + 1));
+  {
+    std::vector<v2::BondSrc> src(n);
+    for (int i = 0; i < n; i++) {
+      if (probs[i].mirror) return c->fail(MPBP_EINVAL, "internal: mirrored problem in the batched gauge sweep");
+      src[i] = v2::BondSrc{probs[i].bond1, probs[i].bond2};
+    }
+    const size_t bsrc = (sizeof(v2::BondSrc) * n + 255) & ~size_t(255), bout = sizeof(int32_t) * hb.size();
+    int rc = ensure_arena(c, c->v2arena, bsrc + bout + 4096);
+    if (rc != MPBP_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->v2arena.base, src.data(), sizeof(v2::BondSrc) * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(v2::k_gather_bonds, dim3(n), dim3(64), 0, st, (const v2::BondSrc*)c->v2arena.base, (int32_t*)(c->v2arena.base + bsrc), L);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hb.data(), c->v2arena.base + bsrc, bout, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  // ---- dimensions of every time step (host: they follow from the bond tables)
+  std::vector<ProbPlan> plan(n);
+  for (int i = 0; i < n; i++) {
+    const EngProb& P = probs[i];
+    ProbPlan& pp = plan[i];
+    const int32_t* b1 = hb.data() + (size_t)i * 2 * (L + 1);
+    const int32_t* b2 = b1 + (L + 1);
+    pp.st.resize(L); pp.lfoff.assign(L + 1, 0); pp.rdim.assign(L + 1, 1);
+    int64_t off = 0;
+    pp.lfoff[L] = off; off += 4;                      // Lf_L = [1]
+    for (int t = L - 1; t >= 1; t--) {
+      StepDims d;
+      d.a = b1[t]; d.an = b1[t + 1]; d.b = b2[t]; d.bn = b2[t + 1];
+      d.r1 = pp.rdim[t + 1];
+      d.rows = d.r1 * P.ny * P.q; d.cols = d.a * d.b; d.kmax = std::min(d.rows, d.cols);
+      pp.rdim[t] = d.kmax;
+      pp.st[t] = d;
+      pp.lfoff[t] = off; off += ((int64_t)d.kmax * d.cols + 3) & ~int64_t(3);
+      pp.y_doubles = std::max<int64_t>(pp.y_doubles, (int64_t)r32i(d.rows) * (r16i(d.cols) + 16));
+      pp.z_doubles = std::max<int64_t>(pp.z_doubles, (int64_t)d.a * P.ny1 * P.q * d.r1 * d.bn);
+      pp.e_doubles = std::max<int64_t>(pp.e_doubles, (int64_t)P.q * d.b * P.ny * d.bn * P.ny1);
+      pp.rows32_max = std::max(pp.rows32_max, r32i(d.rows)); pp.cols_max = std::max(pp.cols_max, d.cols);
+    }
+    pp.lf_doubles = off;
+  }
+  // ---- how many problems fit
+  size_t freeb = 0, totb = 0;
+  hipMemGetInfo(&freeb, &totb);
+  const size_t budget = (size_t)((double)(freeb + c->v2arena.cap) * 0.80);
+  auto al = [](int64_t d) { return ((size_t)d * 8 + 255) & ~size_t(255); };
+  int P = 0; size_t bytes = 0;
+  int nchunk = 1, ntile = 1;
+  std::vector<size_t> per(n);
+  for (int i = 0; i < n; i++) {
+    const int nc = std::max(nchunk, (plan[i].rows32_max + v2::CH - 1) / v2::CH), nt = std::max(ntile, r16i(plan[i].cols_max) / 16 + 1);
+    // aux is sized by the batch maxima: recompute the total when they grow
+    size_t tot = 0;
+    for (int k = 0; k <= i; k++)
+      tot += al(plan[k].y_doubles) + al(plan[k].z_doubles) + al(plan[k].e_doubles) + al(plan[k].lf_doubles) + al(v2::auxlay_doubles(nc, nt)) +
+             (((size_t)(L + 1) * 12 + 255) & ~size_t(255));
+    const size_t desc = (size_t)(i + 1) * L * (sizeof(v2::QrProb) + sizeof(v2::GemmDesc) * (1 + c->q) + sizeof(v2::EDesc) + sizeof(v2::LfDesc)) + 65536;
+    if (i > 0 && tot + desc > budget) break;
+    P = i + 1; bytes = tot + desc; nchunk = nc; ntile = nt;
+  }
+  if (bytes > budget) return c->fail(MPBP_ENOMEM, "batched gauge sweep: one problem needs %zu MiB, %zu MiB available", bytes >> 20, budget >> 20);
+  {
+    int rc = ensure_arena(c, c->v2arena, bytes + 65536);
+    if (rc != MPBP_OK) return rc;
+  }
+  const v2::AuxLay lay = v2::make_auxlay(nchunk, ntile);
+  const int64_t auxd = v2::auxlay_doubles(nchunk, ntile);
+  // ---- carve the arena
+  char* base = c->v2arena.base; size_t used = 0;
+  auto take = [&](size_t b) { char* p = base + used; used += (b + 255) & ~size_t(255); return p; };
+  struct Bufs { double *Y, *Z, *E, *aux, *lf; int64_t* lfoff; int32_t* rdim; };
+  std::vector<Bufs> bf(P);
+  for (int i = 0; i < P; i++) {
+    bf[i].Y = (double*)take(al(plan[i].y_doubles)); bf[i].Z = (double*)take(al(plan[i].z_doubles));
+    bf[i].E = (double*)take(al(plan[i].e_doubles)); bf[i].aux = (double*)take(al(auxd)); bf[i].lf = (double*)take(al(plan[i].lf_doubles));
+    char* tb = take((size_t)(L + 1) * 12);
+    bf[i].lfoff = (int64_t*)tb; bf[i].rdim = (int32_t*)(tb + (size_t)(L + 1) * 8);
+  }
+  // ---- descriptors of all time steps, one upload
+  const int q = probs[0].q;
+  std::vector<v2::QrProb> hq((size_t)P * L);
+  std::vector<v2::GemmDesc> hg1((size_t)P * L), hg2((size_t)P * L * q);
+  std::vector<v2::EDesc> he((size_t)P * L);
+  std::vector<v2::LfDesc> hl((size_t)P * L);
+  std::vector<v2::SetOne> hone(P);
+  std::vector<char> htab((size_t)P * (L + 1) * 12);
+  for (int i = 0; i < P; i++) {
+    const EngProb& Pr = probs[i];
+    if (Pr.q != q) return c->fail(MPBP_EINVAL, "internal: mixed q in one batch");
+    memcpy(htab.data() + (size_t)i * (L + 1) * 12, plan[i].lfoff.data(), (size_t)(L + 1) * 8);
+    memcpy(htab.data() + (size_t)i * (L + 1) * 12 + (size_t)(L + 1) * 8, plan[i].rdim.data(), (size_t)(L + 1) * 4);
+    hone[i].p = bf[i].lf + plan[i].lfoff[L];
+    for (int t = 1; t < L; t++) {
+      const StepDims& d = plan[i].st[t];
+      const size_t k = (size_t)t * P + i;
+      const int ldY = r32i(d.rows);
+      hq[k] = v2::QrProb{bf[i].Y, bf[i].aux, ldY, d.rows, d.cols, d.kmax};
+      hl[k].Lf = bf[i].lf + plan[i].lfoff[t];
+      he[k] = v2::EDesc{Pr.A2 + (int64_t)t * Pr.stride2, Pr.pyy + (int64_t)t * Pr.pyy_tstride, bf[i].E, d.b, d.bn, Pr.ny, Pr.ny1, Pr.ny2, q};
+      const int64_t zld = (int64_t)d.r1 * d.bn;
+      v2::GemmDesc g{};
+      g.S = Pr.A1 + (int64_t)t * Pr.stride1; g.X = bf[i].lf + plan[i].lfoff[t + 1]; g.O = bf[i].Z;
+      g.M = d.a * Pr.ny1 * q; g.N = d.r1 * d.bn; g.K = d.an;
+      g.sro = v2::Map2{d.a, 1, (int64_t)d.a * d.an}; g.sco = lin(d.a);
+      g.xro = lin(d.r1); g.xco = v2::Map2{d.r1, 1, (int64_t)d.r1 * d.an};
+      g.oro = lin(zld); g.oco = lin(1);
+      hg1[k] = g;
+      const int M2 = d.b * Pr.ny, K2 = d.bn * Pr.ny1;
+      for (int xi = 0; xi < q; xi++) {
+        v2::GemmDesc h{};
+        h.S = bf[i].E + (int64_t)xi * M2 * K2; h.X = bf[i].Z + zld * d.a * Pr.ny1 * xi; h.O = bf[i].Y + (int64_t)d.r1 * Pr.ny * xi;
+        h.M = M2; h.N = d.r1 * d.a; h.K = K2;
+        h.sro = lin(1); h.sco = lin(M2);
+        h.xro = v2::Map2{d.bn, d.r1, zld * d.a}; h.xco = v2::Map2{d.r1, 1, zld};
+        h.oro = v2::Map2{d.b, (int64_t)ldY * d.a, d.r1}; h.oco = v2::Map2{d.r1, 1, ldY};
+        hg2[((size_t)t * P + i) * q + xi] = h;
+      }
+    }
+  }
+  v2::QrProb* dq = (v2::QrProb*)take(sizeof(v2::QrProb) * hq.size());
+  v2::GemmDesc* dg1 = (v2::GemmDesc*)take(sizeof(v2::GemmDesc) * hg1.size());
+  v2::GemmDesc* dg2 = (v2::GemmDesc*)take(sizeof(v2::GemmDesc) * hg2.size());
+  v2::EDesc* de = (v2::EDesc*)take(sizeof(v2::EDesc) * he.size());
+  v2::LfDesc* dl = (v2::LfDesc*)take(sizeof(v2::LfDesc) * hl.size());
+  v2::SetOne* done = (v2::SetOne*)take(sizeof(v2::SetOne) * hone.size());
+  if (used > c->v2arena.cap) return c->fail(MPBP_ENOMEM, "internal: gauge-sweep arena accounting (%zu > %zu)", used, c->v2arena.cap);
+  HIPCHK(c, hipMemcpyAsync(dq, hq.data(), sizeof(v2::QrProb) * hq.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dg1, hg1.data(), sizeof(v2::GemmDesc) * hg1.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dg2, hg2.data(), sizeof(v2::GemmDesc) * hg2.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(de, he.data(), sizeof(v2::EDesc) * he.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dl, hl.data(), sizeof(v2::LfDesc) * hl.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(done, hone.data(), sizeof(v2::SetOne) * hone.size(), hipMemcpyHostToDevice, st));
+  for (int i = 0; i < P; i++)
+    HIPCHK(c, hipMemcpyAsync(bf[i].lfoff, htab.data() + (size_t)i * (L + 1) * 12, (size_t)(L + 1) * 12, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));     // the host vectors go out of scope below only after the loop, but keep it simple
+  hipLaunchKernelGGL(v2::k_set_one, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SetOne*)done, P);
+  static const bool force_tall = [] { const char* e = getenv("MPBP_DEBUG_FORCE_TALL"); return e && e[0] == '1'; }();
+  // ---- the time steps
+  std::vector<QrDims> dims(P);
+  for (int t = L - 1; t >= 1; t--) {
+    int maxN1 = 0, maxN2 = 0, rows32m = 0, colsm = 0; int64_t maxE = 0;
+    for (int i = 0; i < P; i++) {
+      const StepDims& d = plan[i].st[t];
+      dims[i] = QrDims{d.rows, d.cols, d.kmax};
+      maxN1 = std::max(maxN1, d.r1 * d.bn); maxN2 = std::max(maxN2, d.r1 * d.a);
+      maxE = std::max<int64_t>(maxE, (int64_t)q * d.b * probs[i].ny * d.bn * probs[i].ny1);
+      rows32m = std::max(rows32m, r32i(d.rows)); colsm = std::max(colsm, d.cols);
+    }
+    const size_t o = (size_t)t * P;
+    hipLaunchKernelGGL(v2::k_build_E, dim3((unsigned)std::min<int64_t>(64, (maxE + 255) / 256), P), dim3(256), 0, st, (const v2::EDesc*)(de + o));
+    hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN1 + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dg1 + o));
+    hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
+    hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN2 + 127) / 128), P * q), dim3(512), 0, st, (const v2::GemmDesc*)(dg2 + o * q));
+    if (qr_batch(st, dq + o, dims, lay, force_tall) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
+    const int gw = std::min(256, std::max(1, (colsm + 3) / 4));
+    hipLaunchKernelGGL(v2::k_maxabs, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
+    hipLaunchKernelGGL(v2::k_lf_write, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), (const v2::LfDesc*)(dl + o), lay);
+  }
+  HIPCHK(c, hipGetLastError());
+  for (int i = 0; i < P; i++) { probs[i].lf = bf[i].lf; probs[i].lfoff = bf[i].lfoff; probs[i].rdim = bf[i].rdim; }
+  *n_done = P;
+  return MPBP_OK;
+}

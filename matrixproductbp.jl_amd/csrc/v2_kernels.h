@@ -548,4 +548,17 @@ __global__ void __launch_bounds__(256) k_lf_write(const QrProb* probs, const LfD
   }
 }
 
+// bond tables of both operands of every problem -> one contiguous buffer [nprob][2][L+1]; Lf_L = 1; grid (nprob)
+struct BondSrc { const int32_t* b1; const int32_t* b2; };
+__global__ void __launch_bounds__(64) k_gather_bonds(const BondSrc* src, int32_t* out, int L) {
+  const BondSrc S = src[blockIdx.x];
+  int32_t* o = out + (long)blockIdx.x * 2 * (L + 1);
+  for (int t = threadIdx.x; t <= L; t += 64) { o[t] = S.b1[t]; o[L + 1 + t] = S.b2[t]; }
+}
+struct SetOne { double* p; };
+__global__ void k_set_one(const SetOne* s, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) *s[i].p = 1.0;
+}
+
 }  // namespace v2
