@@ -20,7 +20,9 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix (= vector) peak, public spec; BASELINE.md section 2
+FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 matrix (= vector) peak, public spec; BASELINE.md section 2
+FP32_MFMA_PEAK_TFLOPS = 157.3   # fp32 matrix peak (north_star asks for this fraction too)
+HBM_PEAK_TBPS = 8.0             # HBM3E spec (about 6.3 TB/s achievable, MI355X_MICROARCH.md)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -39,27 +41,46 @@ def _cpu_heavy_op(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(msgs3, lam, rho, gam, T, Mb, E_per_sweep):
-    """msgs3: the three incoming messages of one degree-3 node (lists of cores) from the device state.
-    Sample: on every host core in parallel one heavy `op` (Kronecker 20x20 -> compress!, 100 SVDs up to
-    400x1600); on one core the cheap parts (one light `op` with `init`, one message finalisation, the
-    belief).  A degree-3 node update = 4 heavy + 3 light ops + 3 finalisations + 1 belief (cavity order,
-    reference src/recursive_bp_factor.jl:140 with CavityTools.cavity)."""
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(node_msgs, lam, rho, gam, T, Mb, E_per_sweep, n_heavy=64):
+    """node_msgs: the incoming messages (lists of cores) of several degree-3 nodes from the device state after the
+    warm-up sweeps.  Sample: >= n_heavy heavy `op`s (Kronecker 20x20 -> compress!, 100 SVDs up
+    to 400x1600) drawn from those nodes' message pairs, one process per host core (all of os.sched_getaffinity);
+    on one core the cheap parts (one light `op` with `init`, one message finalisation, the belief).  A degree-3 node
+    update = 4 heavy + 3 light ops + 3 finalisations + 1 belief (cavity order, reference
+    src/recursive_bp_factor.jl:140 with CavityTools.cavity)."""
     import multiprocessing as mp
     from oracle import mpbp as O
     from oracle.factors import SISFactor
     from oracle.tensor_trains import TensorTrain, TruncBond, compress, normalize, normalize_eachmatrix
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores = len(os.sched_getaffinity(0))
     wi = [SISFactor(lam, rho)] * (T + 1)
     psi = [np.ones((2, 2))] * (T + 1)
     phi = [np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)]
-    B = [O.prob_xy_apply(wi, 2, TensorTrain(m), psi, k, T) for k, m in enumerate(msgs3)]
-    b1 = [c.copy() for c in B[0][0].tensors]
-    b2 = [c.copy() for c in B[1][0].tensors]
+    pairs = []
+    for msgs3 in node_msgs:
+        B = [O.prob_xy_apply(wi, 2, TensorTrain(m), psi, k, T) for k, m in enumerate(msgs3)]
+        for (i, j) in ((0, 1), (1, 2), (0, 2)):
+            pairs.append(([c.copy() for c in B[i][0].tensors], [c.copy() for c in B[j][0].tensors]))
+    n_ops = max(n_heavy, cores)
+    n_ops = ((n_ops + cores - 1) // cores) * cores          # whole rounds: every core busy for the whole sample
+    jobs = [(lam, rho, T, Mb) + pairs[k % len(pairs)] for k in range(n_ops)]
+    t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
-        th = pool.map(_cpu_heavy_op, [(lam, rho, T, Mb, b1, b2)] * cores)
+        th = pool.map(_cpu_heavy_op, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
     t_heavy = float(np.mean(th))
     tr = TruncBond(Mb)
+    B = [O.prob_xy_apply(wi, 2, TensorTrain(m), psi, k, T) for k, m in enumerate(node_msgs[0])]
     a = O.op_kron_compress(wi, B[0], B[1], T, tr)
     init = O.init_train(wi, 2, T)
     t0 = time.perf_counter()
@@ -78,11 +99,13 @@ def cpu_baseline(msgs3, lam, rho, gam, T, Mb, E_per_sweep):
     t_bel = time.perf_counter() - t0
     t_node = 4 * t_heavy + 3 * t_light + 3 * t_fin + t_bel
     rate = cores * 3.0 / t_node
-    return {"value": rate, "unit": "edge-updates/s", "cores": cores, "kind": "port",
-            "s_per_sweep": E_per_sweep / rate,
-            "sample": (f"numpy oracle (LAPACK gesdd), {cores} processes x 1 heavy op (mean {t_heavy:.2f} s) + "
+    return {"value": rate, "unit": "edge-updates/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "nproc": os.cpu_count(), "s_per_sweep": E_per_sweep / rate, "n_heavy_ops_sampled": n_ops,
+            "sample_wall_s": wall,
+            "sample": (f"numpy oracle (LAPACK gesdd), {n_ops} heavy ops from the message pairs of {len(node_msgs)} nodes on "
+                       f"{cores} processes (all host cores; mean {t_heavy:.2f} s per op per core, {wall:.0f} s wall) + "
                        f"light op {t_light:.3f} s + finalisation {t_fin:.3f} s + belief {t_bel:.3f} s on the "
-                       f"post-warm-up messages of node 0; node update = 4 heavy + 3 light + 3 fin + 1 belief "
+                       f"post-warm-up messages; node update = 4 heavy + 3 light + 3 fin + 1 belief "
                        f"= {t_node:.1f} s/core")}
 
 
@@ -91,9 +114,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nodes", type=int, default=1024)
-    ap.add_argument("--T", type=int, default=50)
-    ap.add_argument("--bond", type=int, default=20)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="index into BASELINE.json configs: 1 = SIS 3-regular N=1024 T=50 d=20 (the metric's config, default), "
+                         "2 = Glauber ER N=2048 T=100 d=30, 3 = SIS karate T=200 d=40, 4 = infinite graph k=3 T=200 d=64")
+    ap.add_argument("--nodes", type=int, default=0, help="override the number of nodes (configs 1, 2)")
+    ap.add_argument("--T", type=int, default=0, help="override the chain length")
+    ap.add_argument("--bond", type=int, default=0, help="override the bond cap")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="with one process: run only rank 0's node block of a K-way sharding (what one GPU of K does per sweep)")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="heavy ops timed by the CPU baseline (>= host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (gloo = rehearsal on one GPU)")
     ap.add_argument("--dump-beliefs", default="", help="write rank-0 beliefs + f to this .npy file (parity checks)")
@@ -124,23 +153,68 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    # ---- BASELINE configs[1]: SIS, 3-regular random graph
-    N, T, Mb = args.nodes, args.T, args.bond
+    # ---- workload: inputs of the chosen BASELINE config
+    dflt = {1: (1024, 50, 20), 2: (2048, 100, 30), 3: (34, 200, 40), 4: (1, 200, 64)}[args.config]
+    N, T, Mb = args.nodes or dflt[0], args.T or dflt[1], args.bond or dflt[2]
     lam, rho, gam = 0.1, 0.05, 0.1
-    G = nx.random_regular_graph(3, N, seed=0)
-    g = M.IndexedBiDiGraph(nx.to_numpy_array(G, nodelist=range(N)))
-    E = g.ne()
-    ptr, ine, oute = g.nbr_arrays()
-    slot, S, shards = D.slot_map(ptr, oute, E, world)
-    slot_doubles = (T + 1) * Mb * Mb * 4
-    cores_t = torch.zeros(world * S, slot_doubles, dtype=torch.float64, device=dev)
-    bonds_t = torch.zeros(world * S, T + 2, dtype=torch.int32, device=dev)
-    w = M.SISFactor(lam, rho)
-    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
-    bp = M.mpbp(g, [[w] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb, device=local, slot_of_edge=slot,
-                n_slots=world * S, ext_cores=cores_t.data_ptr(), ext_bonds=bonds_t.data_ptr())
+    nstates = lambda l: 1 if l == 0 else 2          # SIS (sis_bp.jl:18)
+    shardable = args.config in (1, 2)
+    if args.config == 1:
+        G = nx.random_regular_graph(3, N, seed=0)
+        A = nx.to_numpy_array(G, nodelist=range(N))
+        facs = [[M.SISFactor(lam, rho)] * (T + 1)] * N
+        phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+        wl = (f"SIS lambda=0.1 rho=0.05 gamma=0.1 on networkx.random_regular_graph(3,{N},seed=0), T={T}, TruncBond({Mb}), "
+              f"Jacobi sweeps (BASELINE configs[1])")
+    elif args.config == 2:
+        G = nx.gnp_random_graph(N, 4 / (N - 1), seed=0)
+        A = nx.to_numpy_array(G, nodelist=range(N))
+        m0 = -0.6
+        facs = M.glauber_factors(A != 0, 0.5 * A, np.zeros(N), 1.0, T)
+        phi = [[np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+        nstates = lambda l: l + 1                   # HomogeneousGlauberFactor (glauber_bp.jl:32)
+        wl = (f"homogeneous Glauber J=0.5 h=0 beta=1, m0=-0.6 on networkx.gnp_random_graph({N},4/{N - 1},seed=0), T={T}, "
+              f"TruncBond({Mb}), Jacobi sweeps (BASELINE configs[2])")
+    elif args.config == 3:
+        A = np.loadtxt(os.path.join(ROOT, "tests", "golden", "karate.txt"))
+        N = A.shape[0]
+        lam, rho = 0.1, 0.05
+        facs = [[M.SISFactor(lam, rho)] * (T + 1)] * N
+        phi = [[np.array([0.0, 1.0]) if (t == 0 and i == 0) else (np.array([1.0, 0.0]) if t == 0 else np.ones(2))
+                for t in range(T + 1)] for i in range(N)]
+        wl = f"SIS lambda=0.1 rho=0.05, node 0 infected at t=0, karate club (34 nodes, degrees 1..17), T={T}, TruncBond({Mb}) (BASELINE configs[3])"
+    else:
+        A = None
+        lam, rho = 0.1, 0.2
+        wl = f"infinite-graph fixed point (src/infinite_graph.jl), SIS lambda=0.1 rho=0.2 gamma=0.1, k=3, T={T}, TruncBond({Mb}) (BASELINE configs[4])"
+    if A is not None:
+        g = M.IndexedBiDiGraph(A)
+        E = g.ne()
+        ptr, ine, oute = g.nbr_arrays()
+        deg = np.diff(np.asarray(ptr))
+        nshard = world if shardable else 1
+        if world == 1 and args.shard_of > 1 and shardable:
+            nshard = args.shard_of
+        cost = D.node_costs(ptr, 2, Mb, T, nstates=nstates)
+        if shardable and world > 1:
+            slot, S, shards = D.slot_map(ptr, oute, E, world, cost)
+            nslots = world * S
+        else:
+            slot, S, nslots = np.arange(E, dtype=np.int32), E, E
+            shards = D.shard_nodes(ptr, nshard, cost) if nshard > 1 else [(0, N)]
+        slot_doubles = (T + 1) * Mb * Mb * 4
+        cores_t = torch.zeros(nslots, slot_doubles, dtype=torch.float64, device=dev)
+        bonds_t = torch.zeros(nslots, T + 2, dtype=torch.int32, device=dev)
+        bp = M.mpbp(g, facs, 2, T, phi=phi, max_bond=Mb, device=local, slot_of_edge=slot,
+                    n_slots=nslots, ext_cores=cores_t.data_ptr(), ext_bonds=bonds_t.data_ptr())
+        lo, hi = shards[rank if (shardable and world > 1) else 0]
+    else:
+        phi1 = [np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)]
+        bp = M.mpbp_infinite_graph(3, [M.SISFactor(lam, rho)] * (T + 1), 2, phi1, max_bond=Mb, device=local)
+        E, deg, lo, hi, ptr, ine = 3, np.array([3]), 0, 1, [0, 3], None
+        cores_t = bonds_t = None
+    exchange = shardable and world > 1
     bp._L.mpbp_set_profiling(bp._h, 2 if args.phase_profile else 1)
-    lo, hi = shards[rank]
     owned = np.arange(lo, hi, dtype=np.int32)
     trunc = M.TruncBond(Mb)
     ms_orth, n_orth, ms_dev = [], [], []
@@ -150,7 +224,7 @@ def main():
         if record:
             st = bp.last_stats
             ms_orth.append(st.ms_orth); n_orth.append(st.n_orth_launches); ms_dev.append(st.ms_total)
-        if world > 1:
+        if exchange:
             D.allgather_slots(cores_t, bonds_t, S, rank, world)
             torch.cuda.synchronize()
 
@@ -200,50 +274,79 @@ def main():
             print(f"  {n_:10s} {v:10.3f} s  {100 * v / max(tot, 1e-30):5.1f} %", file=sys.stderr)
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = E * args.steps / dt
-        # ---- roofline of the dominant kernel (eng_kernel launches of the cavity `op` levels, rank 0)
+        replicas = world > 1 and not shardable       # configs 3 / 4 do not shard by node: N independent replicas
+        e_job = (int(ptr[hi]) - int(ptr[lo])) if (world == 1 and args.shard_of > 1 and shardable) else E * (world if replicas else 1)
+        value = e_job * args.steps / dt
+        # ---- roofline of the dominant kernel family (the cavity `op` launches: eng_kernel, and for the batched gauge
+        #      sweep its grid kernels; HIP events on the library's stream around every such launch, rank 0)
         b = bp.bonds()
         prof = [int(v) for v in b.max(axis=0)]
-        fl = F.node_update_flops(prof, 3, 2, lambda l: 1 if l == 0 else 2)
-        n_local = hi - lo
+        ex = refalg = 0.0
+        for z in sorted(set(int(d) for d in deg[lo:hi])):
+            if z == 0:
+                continue
+            fl = F.node_update_flops(prof, z, 2, nstates)
+            cnt = int(np.sum(deg[lo:hi] == z))
+            ex += fl["executed_ops"] * cnt * args.steps
+            refalg += fl["reference_ops"] * cnt * args.steps
         launches = int(np.sum(n_orth))
         t_orth = float(np.sum(ms_orth)) * 1e-3
-        ex = fl["executed_ops"] * n_local * args.steps
-        refalg = fl["reference_ops"] * n_local * args.steps
         achieved = ex / t_orth / 1e12 if t_orth > 0 else 0.0
-        # HBM-side bytes per launch come from the committed rocprofv3 --pmc passes of this same command
-        # (bench.py cannot run the profiler on itself); only quoted for the configuration they were taken on
+        # HBM-side bytes per launch: rocprofv3 --pmc passes of this same command, committed under profiles/ (bench.py
+        # cannot run the profiler on itself) - quoted, not measured in this run, and only for the configuration they
+        # were taken on
         traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_eng_kernel.json")
-        if world == 1 and (N, T, Mb) == (1024, 50, 20) and os.path.exists(pmc):
-            with open(pmc) as fh:
-                traffic = json.load(fh)["bytes_per_launch_avg"]
-            traffic_src = "profiles/r01_pmc_eng_kernel.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
+        for rnd in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_eng_kernel.json")
+            if world == 1 and args.config == 1 and (N, T, Mb) == (1024, 50, 20) and os.path.exists(pmc):
+                with open(pmc) as fh:
+                    traffic = json.load(fh)["bytes_per_launch_avg"]
+                traffic_src = f"profiles/{rnd}_pmc_eng_kernel.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch; quoted from the committed profile, not measured in this run)"
+                break
+        avg_launch_s = (t_orth / launches) if launches else None
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "eng_kernel (cavity op levels)", "launches": launches,
-                    "avg_launch_ms": (t_orth / launches * 1e3) if launches else None,
+                    "frac": achieved / FP64_PEAK_TFLOPS, "frac_fp32_mfma": achieved / FP32_MFMA_PEAK_TFLOPS,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "hbm_GBps": (traffic / avg_launch_s / 1e9) if (traffic and avg_launch_s) else None,
+                    "frac_hbm": (traffic / avg_launch_s / 1e12 / HBM_PEAK_TBPS) if (traffic and avg_launch_s) else None,
+                    "kernel": "cavity op launches (v512::eng_kernel; batched gauge sweep kernels when enabled)", "launches": launches,
+                    "avg_launch_ms": (avg_launch_s * 1e3) if launches else None,
                     "flops_per_launch_executed": ex / launches if launches else None,
                     "achieved_reference_algorithmic": refalg / t_orth / 1e12 if t_orth > 0 else 0.0,
                     "frac_reference_algorithmic": (refalg / t_orth / 1e12 / FP64_PEAK_TFLOPS) if t_orth > 0 else 0.0,
                     "note": "achieved / frac count the flops the engine executes (structured contractions + R-only "
-                            "Householder QR + Jacobi on the small factor): the conservative, hardware-utilisation "
-                            "reading; *_reference_algorithmic price the same launches with SURVEY.md 8(d)'s count for "
-                            "the reference algorithm (SVD-based, 601.6 Gflop per node), which the device path "
+                            "Householder QR + Jacobi on the small factor) against the fp64 MFMA peak (78.6 TFLOP/s); "
+                            "frac_fp32_mfma prices the same fp64 work against the fp32 matrix peak north_star names "
+                            "(157.3 TFLOP/s); frac_hbm = memory-side bytes per launch / launch time / 8 TB/s; "
+                            "*_reference_algorithmic price the launches with SURVEY.md 8(d)'s count for the reference "
+                            "algorithm (SVD-based, 601.6 Gflop per node at configs[1]), which the device path "
                             "legitimately undercuts and which can therefore exceed the peak"}
-        out = {"metric": "edge-message updates/sec (and s/sweep), SIS 3-regular N=1024 T=50 d=20",
+        metric = ("edge-message updates/sec (and s/sweep), SIS 3-regular N=1024 T=50 d=20" if args.config == 1
+                  else f"edge-message updates/sec (and s/sweep), BASELINE configs[{args.config}]")
+        par = "1 GPU"
+        if exchange:
+            par = f"nodes sharded over {world} GPU(s) by predicted cost, 1 all-gather/sweep"
+        elif replicas:
+            par = f"{world} independent replicas (this config does not shard by node)"
+        elif world == 1 and args.shard_of > 1 and shardable:
+            par = f"rank 0's node block [{lo},{hi}) of a {args.shard_of}-way sharding, on 1 GPU"
+        out = {"metric": metric,
                "value": value, "unit": "edge-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "s_per_sweep": ms_per_step / 1e3, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"SIS lambda=0.1 rho=0.05 gamma=0.1 on networkx.random_regular_graph(3,{N},seed=0), "
-                                      f"T={T}, TruncBond({Mb}), Jacobi sweeps (BASELINE configs[1])",
-                          "edges": E, "parallelism": f"nodes sharded over {world} GPU(s), 1 all-gather/sweep" if world > 1 else "1 GPU",
+               "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": wl, "edges": int(E), "edge_updates_per_step": int(e_job), "parallelism": par,
                           "bond_profile_max": prof[:5] + ["..."] + prof[-4:]},
                "device_ms_per_step": float(np.mean(ms_dev)), "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
-            e_in = [int(ine[p]) for p in range(ptr[0], ptr[1])]
-            msgs = bp.get_messages(edges=e_in)
-            out["cpu_baseline"] = cpu_baseline([msgs[e] for e in e_in], lam, rho, gam, T, Mb, E)
+        free_b, tot_b = torch.cuda.mem_get_info(dev)
+        out["hbm_in_use_GiB"] = (tot_b - free_b) / 2 ** 30
+        if world == 1 and not args.no_cpu_baseline and args.config == 1:
+            d3 = [i for i in range(lo, hi) if deg[i] == 3][:8]
+            node_msgs = []
+            for i in d3:
+                e_in = [int(ine[p]) for p in range(ptr[i], ptr[i + 1])]
+                msgs = bp.get_messages(edges=e_in)
+                node_msgs.append([msgs[e] for e in e_in])
+            out["cpu_baseline"] = cpu_baseline(node_msgs, lam, rho, gam, T, Mb, E, n_heavy=args.cpu_sample)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

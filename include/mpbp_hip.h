@@ -172,6 +172,19 @@ int mpbp_free_energy(mpbp_ctx* ctx, double* f_node /* [n_nodes] */);
 /* log z_i and sum_j log z_{i->j} of the last update of every node (diagnostics / parity tests) */
 int mpbp_logz(mpbp_ctx* ctx, double* logz_node /* [n_nodes] */, double* logz_msg /* [n_edges] */);
 
+/* Two-time marginals of the beliefs of the listed nodes, computed on the device from the belief trains `bp.b[i]`
+ * (TensorTrains `twovar_marginals`; callers: autocorrelations / autocovariances / alternate_marginals, reference
+ * src/mpbp.jl:245-286): out[k][t][u][x + q*y] = p_{nodes[k]}(x^t = x, x^u = y) for t < u <= t + maxdist (maxdist <= 0:
+ * all), each q x q block normalised, zero elsewhere.  `out`: host, n_nodes * (T+1)^2 * q^2 doubles. */
+int mpbp_twovar_marginals(mpbp_ctx* ctx, const int32_t* nodes, int32_t n_nodes, int32_t maxdist, double* out);
+
+/* Exchange step of the multi-GPU path (replaces the visibility of `bp.mu[idx(e)] = muj`,
+ * src/recursive_bp_factor.jl:177, across GPUs): one in-place RCCL all-gather of the rank-major message slab and one of
+ * the bond table on the context's stream, then a stream synchronise.  The context must have been created with
+ * n_slots = world * slots_per_rank and slot_of_edge mapping every edge into its owner's slot range
+ * [rank * slots_per_rank, (rank+1) * slots_per_rank).  `nccl_comm` is an ncclComm_t of the caller's RCCL. */
+int mpbp_allgather_slots(mpbp_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world, int32_t slots_per_rank);
+
 /* on = 1: per-launch HIP-event timing of the dominant kernel family (mpbp_stats.ms_orth; costs a sync per launch);
  * on = 2: additionally the in-kernel phase timers read by mpbp_phase_profile; 0: off. */
 int mpbp_set_profiling(mpbp_ctx* ctx, int32_t on);

@@ -49,7 +49,7 @@ class Stats(C.Structure):
 EXPORTS = ["mpbp_create", "mpbp_destroy", "mpbp_last_error", "mpbp_slab_layout", "mpbp_slab_pointers",
            "mpbp_set_factor", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
            "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_get_belief_train", "mpbp_pair_beliefs",
-           "mpbp_free_energy", "mpbp_logz", "mpbp_set_profiling", "mpbp_phase_profile", "mpbp_selftest_gemm", "mpbp_selftest_qr", "mpbp_selftest_qr_bench",
+           "mpbp_free_energy", "mpbp_logz", "mpbp_allgather_slots", "mpbp_twovar_marginals", "mpbp_set_profiling", "mpbp_phase_profile", "mpbp_selftest_gemm", "mpbp_selftest_qr", "mpbp_selftest_qr_bench",
            "mpbp_selftest_jacobi_bench", "mpbp_selftest_svd", "mpbp_selftest_qr_batched"]
 
 
@@ -123,6 +123,8 @@ def lib():
     L.mpbp_free_energy.argtypes = [C.c_void_p, dp]
     L.mpbp_logz.argtypes = [C.c_void_p, dp, dp]
     L.mpbp_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    L.mpbp_twovar_marginals.argtypes = [C.c_void_p, ip, C.c_int32, C.c_int32, dp]
+    L.mpbp_allgather_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.mpbp_phase_profile.argtypes = [C.c_void_p, dp, C.c_int32, C.c_int32]
     L.mpbp_selftest_gemm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
     L.mpbp_selftest_qr.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp]

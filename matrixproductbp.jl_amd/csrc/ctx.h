@@ -91,6 +91,10 @@ struct mpbp_ctx {
   int nnz() const { return nbr_ptr[N]; }
   double* slot_cores(int e) const { return d_cores + (int64_t)slot_of_edge[e] * slot_doubles; }
   int32_t* slot_bonds(int e) const { return d_bonds + (int64_t)slot_of_edge[e] * (L + 1); }
+  // incoming messages of a pass: the live slab, or the snapshot of a split Jacobi sweep (mpbp_sweep)
+  double* snap_cores = nullptr; int32_t* snap_bonds = nullptr;
+  const double* read_slot_cores(int e) const { return (snap_cores ? snap_cores : d_cores) + (int64_t)slot_of_edge[e] * slot_doubles; }
+  const int32_t* read_slot_bonds(int e) const { return (snap_bonds ? snap_bonds : d_bonds) + (int64_t)slot_of_edge[e] * (L + 1); }
 };
 
 // grows an arena (contents are NOT preserved); used between launches only

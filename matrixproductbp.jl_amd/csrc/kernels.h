@@ -455,6 +455,136 @@ __global__ void pair_kernel(const PairProb* probs, int L) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two-time marginals of the belief trains: p_i(x^t, x^u), t < u <= t + maxdist (TensorTrains `twovar_marginals`,
+// used by autocorrelations / autocovariances / alternate_marginals, reference src/mpbp.jl:245-286).
+//   tv_env_kernel: left and right environments of the x-summed cores (rescaled by max-abs), one workgroup per node
+//   tv_kernel:     one workgroup per (start time t, node): mid = l_{t-1} b[t][:,:,x], then for u = t+1 ..:
+//                  p[x,y] = mid[x,:] b[u][:,:,y] r_{u+1},  mid <- mid (sum_y b[u][:,:,y]) rescaled
+// ------------------------------------------------------------------------------------------------
+struct TvProb {
+  const double* cores; const int32_t* bond; int64_t stride;   // belief train: core t at cores + t*stride, [b_t, b_{t+1}, q]
+  double* lenv; double* renv;                                 // [(L+1) * bmax] each: lenv[t] before core t, renv[t] after core t-1
+  double* out;                                                // [L][L][q*q] (device), zero where undefined
+  int32_t q, bmax;
+};
+
+__global__ void __launch_bounds__(256) tv_env_kernel(const TvProb* probs, int L) {
+  const TvProb P = probs[blockIdx.x];
+  __shared__ double red[8];
+  const int tid = threadIdx.x, q = P.q;
+  auto wgmax = [&](double v) {
+    v = wg::wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  };
+  // left: lenv[0] = [1]; lenv[t+1][n] = sum_m lenv[t][m] S_t[m,n],  S_t = sum_x b[t][:,:,x]
+  if (tid == 0) { P.lenv[0] = 1.0; P.renv[(int64_t)L * P.bmax] = 1.0; }
+  __syncthreads();
+  for (int t = 0; t < L; t++) {
+    const int a = P.bond[t], an = P.bond[t + 1];
+    const double* c = P.cores + (int64_t)t * P.stride;
+    const double* lv = P.lenv + (int64_t)t * P.bmax;
+    double* lo = P.lenv + (int64_t)(t + 1) * P.bmax;
+    double mx = 0.0, mine = 0.0;
+    if (tid < an) {
+      double s = 0.0;
+      for (int x = 0; x < q; x++)
+        for (int m = 0; m < a; m++) s += lv[m] * c[m + (int64_t)a * (tid + (int64_t)an * x)];
+      mine = s; mx = fabs(s);
+    }
+    mx = wgmax(mx);
+    if (tid < an) lo[tid] = (mx > 0.0 && isfinite(mx)) ? mine / mx : mine;
+    __syncthreads();
+  }
+  for (int t = L - 1; t >= 0; t--) {
+    const int a = P.bond[t], an = P.bond[t + 1];
+    const double* c = P.cores + (int64_t)t * P.stride;
+    const double* rv = P.renv + (int64_t)(t + 1) * P.bmax;
+    double* ro = P.renv + (int64_t)t * P.bmax;
+    double mx = 0.0, mine = 0.0;
+    if (tid < a) {
+      double s = 0.0;
+      for (int x = 0; x < q; x++)
+        for (int n = 0; n < an; n++) s += c[tid + (int64_t)a * (n + (int64_t)an * x)] * rv[n];
+      mine = s; mx = fabs(s);
+    }
+    mx = wgmax(mx);
+    if (tid < a) ro[tid] = (mx > 0.0 && isfinite(mx)) ? mine / mx : mine;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) tv_kernel(const TvProb* probs, int L, int maxdist) {
+  const TvProb P = probs[blockIdx.y];
+  const int t = blockIdx.x, tid = threadIdx.x, q = P.q;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* mid = lds;                    // [q][bmax]
+  double* nmid = lds + q * P.bmax;      // [q][bmax]
+  double* pacc = nmid + q * P.bmax;     // [4 waves][16]
+  double* red = pacc + 64;              // [8]
+  double* out = P.out + (int64_t)t * L * q * q;
+  {
+    const int a = P.bond[t], an = P.bond[t + 1];
+    const double* c = P.cores + (int64_t)t * P.stride;
+    const double* lv = P.lenv + (int64_t)t * P.bmax;
+    for (int idx = tid; idx < q * an; idx += 256) {
+      const int n = idx % an, x = idx / an;
+      double s = 0.0;
+      for (int m = 0; m < a; m++) s += lv[m] * c[m + (int64_t)a * (n + (int64_t)an * x)];
+      mid[x * P.bmax + n] = s;
+    }
+  }
+  __syncthreads();
+  const int uend = min(L, t + maxdist + 1);
+  for (int u = t + 1; u < uend; u++) {
+    const int a = P.bond[u], an = P.bond[u + 1];
+    const double* c = P.cores + (int64_t)u * P.stride;
+    const double* rv = P.renv + (int64_t)(u + 1) * P.bmax;
+    double pl[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pl[k] = 0.0;
+    double mx = 0.0;
+    for (int n = tid; n < an; n += 256) {
+      const double r = rv[n];
+      for (int x = 0; x < q; x++) {
+        double tot = 0.0;
+        for (int y = 0; y < q; y++) {
+          const double* col = c + (int64_t)a * (n + (int64_t)an * y);
+          double s = 0.0;
+          for (int m = 0; m < a; m++) s += mid[x * P.bmax + m] * col[m];
+          tot += s;
+#pragma unroll
+          for (int k = 0; k < 16; k++) pl[k] += (k == x + q * y) ? s * r : 0.0;
+        }
+        nmid[x * P.bmax + n] = tot;
+        mx = fmax(mx, fabs(tot));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) pl[k] = wg::wave_sum(pl[k]);
+    mx = wg::wave_max(mx);
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) pacc[(tid >> 6) * 16 + k] = pl[k];
+      red[tid >> 6] = mx;
+    }
+    __syncthreads();
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (tid < q * q) {
+      double tot = 0.0;
+      for (int k = 0; k < q * q; k++) tot += pacc[k] + pacc[16 + k] + pacc[32 + k] + pacc[48 + k];
+      const double v = pacc[tid] + pacc[16 + tid] + pacc[32 + tid] + pacc[48 + tid];
+      out[(int64_t)u * q * q + tid] = v / tot;
+    }
+    const double inv = (mx > 0.0 && isfinite(mx)) ? 1.0 / mx : 1.0;
+    for (int idx = tid; idx < q * an; idx += 256) { const int n = idx % an, x = idx / an; mid[x * P.bmax + n] = nmid[x * P.bmax + n] * inv; }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // self-test kernels (building blocks against host references; used by tests/)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WG_THREADS) st_gemm_kernel(int M, int N, int K, const double* A, const double* B, double* C) {

@@ -520,21 +520,13 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   return MPBP_OK;
 }
 
-extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_trunc trunc, double damp, mpbp_stats* stats) {
-  if (!c) return MPBP_EINVAL;
-  if (n_nodes < 0 || (n_nodes > 0 && !nodes)) return c->fail(MPBP_EINVAL, "bad node list");
-  if (!(damp >= 0.0 && damp < 1.0)) return c->fail(MPBP_EINVAL, "damp must satisfy 0 <= damp < 1 (reference src/recursive_bp_factor.jl:169)");
-  if (trunc.kind < 0 || trunc.kind > 3) return c->fail(MPBP_EINVAL, "unknown truncation kind %d", trunc.kind);
-  if (trunc.kind != MPBP_TRUNC_THRESH && trunc.mprime < 1) return c->fail(MPBP_EINVAL, "mprime must be >= 1");
-  hipSetDevice(c->device);
-  if (c->tables_dirty) { int rc = build_tables(c); if (rc != MPBP_OK) return rc; }
+// internal: the work trains of this node list do not fit the device - the caller splits the list
+#define MPBP_ESPLIT_INTERNAL (-1000)
+
+// One pass over `nodes` (validated by mpbp_sweep).  Reads the incoming messages from c->read_cores / read_bonds (the
+// live slab, or the snapshot taken by mpbp_sweep when a Jacobi sweep has to be split), writes the live slab.
+static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_trunc trunc, double damp, mpbp_stats* stats, bool may_split) {
   const int L = c->L, q = c->q, cap = c->cap;
-  std::vector<char> seen(c->N, 0);
-  for (int k = 0; k < n_nodes; k++) {
-    if (nodes[k] < 0 || nodes[k] >= c->N) return c->fail(MPBP_EINVAL, "node id %d out of range", nodes[k]);
-    if (seen[nodes[k]]) return c->fail(MPBP_EINVAL, "node %d listed twice", nodes[k]);
-    seen[nodes[k]] = 1;
-  }
   EventPair evs;
   hipEvent_t ev0 = evs.a, ev1 = evs.b;
   hipEventRecord(ev0, c->stream);
@@ -635,6 +627,14 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
     }
     if (ok) break;
     if (pass == 1) return c->fail(MPBP_ENOMEM, "work arena too small");
+    if (may_split && n_nodes > 1) {
+      // every work train of the pass is resident at once (config 3 on one GPU: 300 GB for the 2048 nodes): past 45 %
+      // of what the context can get, the node list is split and the halves run one after the other
+      size_t freeb = 0, totb = 0;
+      hipMemGetInfo(&freeb, &totb);
+      const size_t reach = freeb + c->arena.cap + c->scratch.cap + c->v2arena.cap;
+      if (c->arena.want > (size_t)(0.45 * (double)reach)) return MPBP_ESPLIT_INTERNAL;
+    }
     int rc = ensure_arena(c, c->arena, c->arena.want + (1 << 20));
     if (rc != MPBP_OK) return rc;
   }
@@ -648,7 +648,7 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
         const int ein = c->in_edge[p];
         DevTrain& o = tr[plans[k].src[j]];
         PrepProb P{};
-        P.msg = c->slot_cores(ein); P.mbond = c->slot_bonds(ein); P.mstride = c->core_stride;
+        P.msg = c->read_slot_cores(ein); P.mbond = c->read_slot_bonds(ein); P.mstride = c->core_stride;
         P.tab = c->d_tab + c->pxy_off[p]; P.tab_tstride = c->pxy_tstride[p];
         P.out = o.cores; P.obond = o.bonds; P.ostride = o.stride; P.ologz = o.logz; P.ny1 = f.ny[1]; P.q = q;
         pp.push_back(P);
@@ -899,6 +899,137 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
   c->last = st;
   if (stats) *stats = st;
   if (hs.capacity_flag) return c->fail(MPBP_ECAPACITY, "a truncated bond exceeded max_bond=%d; results were clamped", cap);
+  return MPBP_OK;
+}
+
+static void merge_stats(mpbp_stats& a, const mpbp_stats& b) {
+  a.maxerr = std::max(a.maxerr, b.maxerr); a.n_compress += b.n_compress;
+  a.nan_flag |= b.nan_flag; a.capacity_flag |= b.capacity_flag; a.jacobi_not_converged |= b.jacobi_not_converged;
+  a.ms_total += b.ms_total; a.ms_orth += b.ms_orth; a.n_orth_launches += b.n_orth_launches;
+  a.jacobi_sweeps += b.jacobi_sweeps; a.jacobi_calls += b.jacobi_calls;
+}
+
+static int sweep_split(mpbp_ctx* c, const int32_t* nodes, int32_t n, mpbp_trunc trunc, double damp, mpbp_stats* acc) {
+  mpbp_stats st{};
+  int rc = sweep_nodes(c, nodes, n, trunc, damp, &st, true);
+  if (rc == MPBP_ESPLIT_INTERNAL) {
+    const int h = n / 2;
+    rc = sweep_split(c, nodes, h, trunc, damp, acc);
+    if (rc != MPBP_OK && rc != MPBP_ECAPACITY) return rc;
+    const int rc2 = sweep_split(c, nodes + h, n - h, trunc, damp, acc);
+    return rc2 != MPBP_OK ? rc2 : rc;
+  }
+  if (rc == MPBP_OK || rc == MPBP_ECAPACITY) merge_stats(*acc, st);
+  return rc;
+}
+
+extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_trunc trunc, double damp, mpbp_stats* stats) {
+  if (!c) return MPBP_EINVAL;
+  if (n_nodes < 0 || (n_nodes > 0 && !nodes)) return c->fail(MPBP_EINVAL, "bad node list");
+  if (!(damp >= 0.0 && damp < 1.0)) return c->fail(MPBP_EINVAL, "damp must satisfy 0 <= damp < 1 (reference src/recursive_bp_factor.jl:169)");
+  if (trunc.kind < 0 || trunc.kind > 3) return c->fail(MPBP_EINVAL, "unknown truncation kind %d", trunc.kind);
+  if (trunc.kind != MPBP_TRUNC_THRESH && trunc.mprime < 1) return c->fail(MPBP_EINVAL, "mprime must be >= 1");
+  hipSetDevice(c->device);
+  if (c->tables_dirty) { int rc = build_tables(c); if (rc != MPBP_OK) return rc; }
+  std::vector<char> seen(c->N, 0);
+  for (int k = 0; k < n_nodes; k++) {
+    if (nodes[k] < 0 || nodes[k] >= c->N) return c->fail(MPBP_EINVAL, "node id %d out of range", nodes[k]);
+    if (seen[nodes[k]]) return c->fail(MPBP_EINVAL, "node %d listed twice", nodes[k]);
+    seen[nodes[k]] = 1;
+  }
+  c->snap_cores = nullptr; c->snap_bonds = nullptr;
+  mpbp_stats st{};
+  int rc = sweep_nodes(c, nodes, n_nodes, trunc, damp, &st, true);
+  if (rc == MPBP_ESPLIT_INTERNAL) {
+    // The listed nodes are updated from the messages at entry (Jacobi semantics of one call): the halves read a
+    // snapshot of the slab, so that the split is invisible in the results.
+    const size_t cb = sizeof(double) * (size_t)c->slot_doubles * c->nslots, bb = sizeof(int32_t) * (size_t)(c->L + 1) * c->nslots;
+    void* snap = nullptr;
+    hipError_t e = hipMalloc(&snap, cb + bb + 256);
+    if (e != hipSuccess) return c->fail(MPBP_ENOMEM, "hipMalloc(%zu MiB message snapshot for a split sweep) failed", (cb + bb) >> 20);
+    hipMemcpyAsync(snap, c->d_cores, cb, hipMemcpyDeviceToDevice, c->stream);
+    hipMemcpyAsync((char*)snap + ((cb + 255) & ~size_t(255)), c->d_bonds, bb, hipMemcpyDeviceToDevice, c->stream);
+    c->snap_cores = (double*)snap; c->snap_bonds = (int32_t*)((char*)snap + ((cb + 255) & ~size_t(255)));
+    st = mpbp_stats{};
+    rc = sweep_split(c, nodes, n_nodes, trunc, damp, &st);
+    hipStreamSynchronize(c->stream);
+    c->snap_cores = nullptr; c->snap_bonds = nullptr;
+    hipFree(snap);
+    c->last = st;
+  }
+  if (stats) *stats = c->last;
+  return rc;
+}
+
+// Two-time marginals of the listed nodes' beliefs on the device (reference src/mpbp.jl:245-286 via TensorTrains
+// `twovar_marginals`): out[k][t][u][x + q*y] = p_{nodes[k]}(x^t = x, x^u = y) for t < u <= t + maxdist, 0 elsewhere.
+extern "C" int mpbp_twovar_marginals(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, int32_t maxdist, double* out) {
+  if (!c || !out || n_nodes < 0 || (n_nodes > 0 && !nodes)) return MPBP_EINVAL;
+  if (!c->d_btrain) return c->fail(MPBP_EUNSUPPORTED, "belief trains are not kept on this context (not enough device memory)");
+  if (n_nodes == 0) return MPBP_OK;
+  hipSetDevice(c->device);
+  const int L = c->L, q = c->q;
+  if (maxdist < 1 || maxdist > L) maxdist = L;
+  const int bmax = q * c->cap;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<int32_t> b0(c->N);
+  HIPCHK(c, hipMemcpy2D(b0.data(), sizeof(int32_t), c->d_bbond, sizeof(int32_t) * (L + 1), sizeof(int32_t), c->N, hipMemcpyDeviceToHost));
+  const size_t env_d = (size_t)(L + 1) * bmax, out_d = (size_t)L * L * q * q;
+  const size_t per = sizeof(double) * (2 * env_d + out_d);
+  int rc = ensure_arena(c, c->scratch, per * n_nodes + sizeof(TvProb) * n_nodes + 8192);
+  if (rc != MPBP_OK) return rc;
+  std::vector<TvProb> tp(n_nodes);
+  char* base = c->scratch.base + ((sizeof(TvProb) * n_nodes + 255) & ~size_t(255));
+  for (int k = 0; k < n_nodes; k++) {
+    const int i = nodes[k];
+    if (i < 0 || i >= c->N) return c->fail(MPBP_EINVAL, "node %d out of range", i);
+    if (b0[i] == 0) return c->fail(MPBP_EINVAL, "node %d has not been updated yet", i);
+    double* d = (double*)(base + per * k);
+    tp[k] = TvProb{c->d_btrain + (int64_t)i * c->bt_slot, c->d_bbond + (int64_t)i * (L + 1), c->bt_stride, d, d + env_d, d + 2 * env_d, q, bmax};
+  }
+  HIPCHK(c, hipMemcpyAsync(c->scratch.base, tp.data(), sizeof(TvProb) * n_nodes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(base, 0, per * n_nodes, c->stream));
+  hipLaunchKernelGGL(tv_env_kernel, dim3(n_nodes), dim3(256), 0, c->stream, (const TvProb*)c->scratch.base, L);
+  const size_t lds = sizeof(double) * (2 * (size_t)q * bmax + 64 + 8);
+  HIPCHK(c, hipFuncSetAttribute((const void*)tv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(tv_kernel, dim3(L, n_nodes), dim3(256), lds, c->stream, (const TvProb*)c->scratch.base, L, maxdist);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < n_nodes; k++)
+    HIPCHK(c, hipMemcpy(out + out_d * k, base + per * k + sizeof(double) * 2 * env_d, sizeof(double) * out_d, hipMemcpyDeviceToHost));
+  return MPBP_OK;
+}
+
+// ================================================================================================
+// the exchange step of the multi-GPU path, inside the boundary
+// ================================================================================================
+#include <dlfcn.h>
+// One in-place all-gather of the rank-major message slab (+ one of the bond table) over RCCL on the context's
+// stream, then a stream synchronise: makes the messages written by `mpbp_sweep` on every rank visible on all of
+// them - the `bp.mu[idx(e)] = muj` of the reference (src/recursive_bp_factor.jl:177) across GPUs.
+// `nccl_comm`: an ncclComm_t of the RCCL library this process uses (the symbol is looked up among the loaded
+// libraries first, so a host that already talks to RCCL - torch.distributed, MPI.jl + RCCL - shares its copy).
+extern "C" int mpbp_allgather_slots(mpbp_ctx* c, void* nccl_comm, int32_t rank, int32_t world, int32_t slots_per_rank) {
+  if (!c) return MPBP_EINVAL;
+  if (!nccl_comm || world < 1 || rank < 0 || rank >= world || slots_per_rank < 1 || (int64_t)world * slots_per_rank != c->nslots)
+    return c->fail(MPBP_EINVAL, "mpbp_allgather_slots: need world * slots_per_rank == n_slots (%d) and 0 <= rank < world", c->nslots);
+  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+  static allgather_fn fn = nullptr;
+  if (!fn) {
+    fn = (allgather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather");
+    if (!fn) {
+      void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (h) fn = (allgather_fn)dlsym(h, "ncclAllGather");
+    }
+    if (!fn) return c->fail(MPBP_EUNSUPPORTED, "ncclAllGather not found: load RCCL (librccl.so) into the process first");
+  }
+  hipSetDevice(c->device);
+  const size_t cb = sizeof(double) * (size_t)c->slot_doubles * slots_per_rank, bb = sizeof(int32_t) * (size_t)(c->L + 1) * slots_per_rank;
+  int rc = fn((const char*)c->d_cores + cb * rank, c->d_cores, cb, /*ncclInt8*/ 0, nccl_comm, c->stream);
+  if (rc == 0) rc = fn((const char*)c->d_bonds + bb * rank, c->d_bonds, bb, 0, nccl_comm, c->stream);
+  if (rc != 0) return c->fail(MPBP_EHIP, "ncclAllGather failed with ncclResult_t %d", rc);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return MPBP_OK;
 }
 

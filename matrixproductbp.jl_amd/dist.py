@@ -10,24 +10,45 @@ from __future__ import annotations
 import numpy as np
 
 
-def shard_nodes(nbr_ptr, world):
-    """Contiguous node blocks with (nearly) equal numbers of out-edges.  Returns list of (lo, hi)."""
+def node_costs(nbr_ptr, q, max_bond, T, nstates=None):
+    """Predicted cost of updating each node (executed flops of its cavity products and finalisations,
+    ``flops.node_update_flops`` on the saturated bond profile): grows like (3z-2) M^6-ish with the degree z and with
+    nstates(l) along the cavity, so edge counts are a poor proxy on heterogeneous graphs."""
+    from . import flops as F
+    nbr_ptr = np.asarray(nbr_ptr, dtype=np.int64)
+    deg = np.diff(nbr_ptr)
+    L = T + 1
+    prof = [min(max_bond, (q * q) ** min(t, L - t)) if min(t, L - t) < 32 else max_bond for t in range(L + 1)]
+    ny = (lambda l: 1 if l == 0 else 2) if nstates is None else nstates
+    by_deg = {}
+    for z in sorted(set(int(d) for d in deg)):
+        by_deg[z] = 1.0 if z == 0 else float(F.node_update_flops(prof, z, q, ny)["executed_total"])
+    return np.array([by_deg[int(d)] for d in deg])
+
+
+def shard_nodes(nbr_ptr, world, cost=None):
+    """Contiguous node blocks of (nearly) equal total cost.  ``cost``: per-node weights (``node_costs``); default =
+    out-edge counts (exact for regular graphs).  Returns list of (lo, hi)."""
     nbr_ptr = np.asarray(nbr_ptr, dtype=np.int64)
     N = nbr_ptr.size - 1
-    tot = int(nbr_ptr[-1])
+    cum = nbr_ptr.astype(np.float64) if cost is None else np.concatenate([[0.0], np.cumsum(np.asarray(cost, dtype=np.float64))])
+    tot = float(cum[-1])
     bounds = [0]
     for r in range(1, world):
         target = tot * r / world
-        j = int(np.searchsorted(nbr_ptr, target, side="left"))
+        j = int(np.searchsorted(cum, target, side="left"))
+        # the boundary that leaves the prefix closest to the target
+        if j > 0 and abs(cum[j - 1] - target) < abs(cum[min(j, N)] - target):
+            j -= 1
         bounds.append(min(max(j, bounds[-1]), N))
     bounds.append(N)
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
 
 
-def slot_map(nbr_ptr, out_edge, n_edges, world):
+def slot_map(nbr_ptr, out_edge, n_edges, world, cost=None):
     """slot_of_edge[e]: rank-major, padded.  Edge e is owned by the rank that owns its source node
     (= the node that has e among its out-edges).  Returns (slot_of_edge, slots_per_rank, shards)."""
-    shards = shard_nodes(nbr_ptr, world)
+    shards = shard_nodes(nbr_ptr, world, cost)
     nbr_ptr = np.asarray(nbr_ptr)
     out_edge = np.asarray(out_edge)
     owner_edges = []

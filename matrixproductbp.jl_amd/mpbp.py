@@ -387,6 +387,13 @@ def onebpiter(bp: MPBP, i, svd_trunc=None, damp=0.0):
         svd_trunc.maxerr = max(svd_trunc.maxerr, st.maxerr)
     if st.nan_flag:
         print("Error: NaN in tensor train")      # reference: @error, then continues
+    if st.jacobi_not_converged:
+        # the one-sided Jacobi behind an SVDTrunc decision hit its sweep limit: singular vectors of that step are
+        # less accurate than LAPACK's would be - never silently (the messages are still stored, as after a NaN)
+        import warnings
+        warnings.warn("libmpbp_hip: a Jacobi SVD did not converge within its sweep limit in this update "
+                      "(mpbp_stats.jacobi_not_converged); results of this sweep may deviate from the reference",
+                      RuntimeWarning, stacklevel=2)
     return None
 
 
@@ -438,20 +445,35 @@ def twovar_marginals(cores, maxdist=None):
     return out
 
 
+def beliefs_tu(bp: MPBP, sites=None, maxdist=None):
+    """`beliefs_tu` (src/mpbp.jl:239-243): two-time marginals `out[i][t][u][x_t, x_u]` (t < u <= t + maxdist, else
+    None) of the listed nodes, computed on the device from the belief trains (mpbp_twovar_marginals)."""
+    sites = list(range(bp.g.nv())) if sites is None else list(sites)
+    L, q = bp.T + 1, bp.q
+    nodes = np.ascontiguousarray(sites, dtype=np.int32)
+    buf = np.zeros(len(sites) * L * L * q * q)
+    md = 0 if maxdist is None else int(maxdist)
+    _lib.check(bp._L.mpbp_twovar_marginals(bp._h, _ip(nodes), int(nodes.size), md, _dp(buf)), bp._h)
+    arr = buf.reshape((len(sites), L, L, q, q))           # [k][t][u][y][x] in memory order x fastest
+    md = L if maxdist is None else int(maxdist)
+    return [[[arr[k, t, u].T.copy() if t < u <= t + md else None for u in range(L)] for t in range(L)]
+            for k in range(len(sites))]
+
+
 def autocorrelations(f, bp: MPBP, sites=None, maxdist=None):
-    """src/mpbp.jl:245-255: `r[i][t, u] = <f(x_i^t) f(x_i^u)>` for t < u (0 elsewhere)."""
-    sites = range(bp.g.nv()) if sites is None else sites
+    """src/mpbp.jl:245-255: `r[i][t, u] = <f(x_i^t) f(x_i^u)>` for t < u (0 elsewhere); the O(T^2) two-time
+    marginals come from the device (mpbp_twovar_marginals), only the q x q contraction with f runs here."""
+    sites = list(range(bp.g.nv())) if sites is None else list(sites)
+    L, q = bp.T + 1, bp.q
+    nodes = np.ascontiguousarray(sites, dtype=np.int32)
+    buf = np.zeros(len(sites) * L * L * q * q)
+    md = 0 if maxdist is None else int(maxdist)
+    _lib.check(bp._L.mpbp_twovar_marginals(bp._h, _ip(nodes), int(nodes.size), md, _dp(buf)), bp._h)
+    arr = buf.reshape((len(sites), L, L, q, q))
     out = []
-    for i in sites:
-        tv = twovar_marginals(belief_train(bp, i), maxdist)
-        L = bp.T + 1
-        r = np.zeros((L, L))
-        fx = np.array([f(x + 1, i) for x in range(bp.q)])
-        for t in range(L):
-            for u in range(t + 1, L):
-                if tv[t][u] is not None:
-                    r[t, u] = fx @ tv[t][u] @ fx
-        out.append(r)
+    for k, i in enumerate(sites):
+        fx = np.array([f(x + 1, i) for x in range(q)])
+        out.append(np.einsum("tuyx,x,y->tu", arr[k], fx, fx))
     return out
 
 

@@ -64,7 +64,70 @@ def star_exact():
                         pair_marginals=np.array(exact_pair_marginals(bp, p)), Z=Z)
 
 
+def _save_sweeps(bp, sweeps, trunc, name, extra, jacobi=True):
+    out = dict(extra)
+    import time
+    for s in range(sweeps):
+        t0 = time.time()
+        O.iterate(bp, maxiter=1, svd_trunc=trunc, tol=0.0, shuffle_nodes=False, jacobi=jacobi)
+        out[f"beliefs_{s}"] = np.array(O.beliefs(bp))
+        out[f"f_{s}"] = bp.f.copy()
+        print(name, "sweep", s, f"{time.time() - t0:.1f} s", "max bond", max(max(m.bonds) for m in bp.mu), flush=True)
+    out["bonds"] = np.array([m.bonds for m in bp.mu])
+    if jacobi:
+        pb, lz = O.pair_beliefs(bp)
+        out["pair_beliefs"] = np.array(pb)
+        out["pair_logz"] = lz
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def bondcap_infinite(T=8, Mb=64, iters=5, name="sis_inf_k3_T8_M64.npz"):
+    """BASELINE configs[4] at its bond cap (TruncBond(64): product bond 4096), chain shortened to T = 8 so that the
+    oracle finishes offline (reference test/sis_infinite_graph.jl:3-12 scaled; sequential in-place iterations)."""
+    k, gam, lam, rho = 3, 0.1, 0.1, 0.2
+    phi = [np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)]
+    bp = O.mpbp_infinite_graph(k, [OF.SISFactor(lam, rho) for _ in range(T + 1)], 2, phi)
+    _save_sweeps(bp, iters, OT.TruncBond(Mb), name, {"params": np.array([k, T, Mb, iters, lam, rho, gam])}, jacobi=False)
+
+
+def bondcap_karate(T=6, Mb=40, sweeps=5, name="sis_karate8_T6_M40.npz"):
+    """BASELINE configs[3] at its bond cap (TruncBond(40): product bond 1600) on the induced subgraph of the karate
+    club on node 0 and its first 7 neighbours (node 0 keeps degree 7), T = 6."""
+    Afull = np.loadtxt(os.path.join(HERE, "karate.txt"))
+    nb = [0] + list(np.nonzero(Afull[:, 0])[0][:7])
+    A = Afull[np.ix_(nb, nb)]
+    N = len(nb)
+    lam, rho = 0.1, 0.05
+    phi = [[np.array([0.0, 1.0]) if (t == 0 and i == 0) else (np.array([1.0, 0.0]) if t == 0 else np.ones(2))
+            for t in range(T + 1)] for i in range(N)]
+    bp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    _save_sweeps(bp, sweeps, OT.TruncBond(Mb), name, {"A": A, "params": np.array([N, T, Mb, sweeps, lam, rho])})
+
+
+def bondcap_glauber(T=6, Mb=30, sweeps=5, name="glauber_er8_T6_M30.npz"):
+    """BASELINE configs[2] at its bond cap (TruncBond(30): product bond 900, nstates = l+1 growing to degree 5) on an
+    8-node Erdos-Renyi graph that has a node of degree >= 5, T = 6 (glauber_bp.jl:22-44,128-131)."""
+    N = 8
+    for seed in range(100):
+        G = nx.gnp_random_graph(N, 4 / 7, seed=seed)
+        deg = [d for _, d in G.degree()]
+        if max(deg) >= 5 and nx.is_connected(G) and sum(deg) <= 28:
+            break
+    A = nx.to_numpy_array(G, nodelist=range(N))
+    J = 0.5 * A
+    h = np.zeros(N)
+    m0 = -0.6
+    phi = [[np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    bp = O.mpbp(O.IndexedBiDiGraph(A), OF.glauber_factors(A != 0, J, h, 1.0, T), [2] * N, T, phi=phi)
+    _save_sweeps(bp, sweeps, OT.TruncBond(Mb), name, {"A": A, "params": np.array([N, T, Mb, sweeps, 0.5, 0.0, 1.0, m0, seed])})
+
+
 if __name__ == "__main__":
+    if "--bondcap" in sys.argv:
+        # fixtures at the bond caps of BASELINE configs[2..4] (reduced N / T); minutes to tens of minutes each:
+        #   OPENBLAS_NUM_THREADS=4 python tests/golden/make_golden.py --bondcap glauber|karate|infinite
+        {"glauber": bondcap_glauber, "karate": bondcap_karate, "infinite": bondcap_infinite}[sys.argv[sys.argv.index("--bondcap") + 1]]()
+        sys.exit(0)
     known_answer()
     rrg_sweeps()
     star_exact()

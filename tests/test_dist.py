@@ -81,3 +81,63 @@ def test_allgather_exchange_world2_gloo():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == res[1][2]
+
+
+def test_cost_model_balances_config3_er_graph():
+    """BASELINE configs[2]: homogeneous Glauber on gnp_random_graph(2048, 4/2047, seed=0), T=100, TruncBond(30), 8 ranks.
+    Degrees run from 0 to >= 9 and nstates = l+1 grows along the cavity: contiguous blocks cut by predicted cost stay
+    within 10 % of the mean, blocks cut by edge counts do not."""
+    import networkx as nx
+    import mpbp_amd as M
+    from mpbp_amd import dist as D
+    N = 2048
+    g = M.IndexedBiDiGraph(nx.to_numpy_array(nx.gnp_random_graph(N, 4 / (N - 1), seed=0), nodelist=range(N)))
+    ptr, ine, oute = g.nbr_arrays()
+    cost = D.node_costs(ptr, 2, 30, 100, nstates=lambda l: l + 1)
+    assert cost.min() > 0 and cost.max() / np.median(cost) > 5
+    for world in (2, 4, 8):
+        sh = D.shard_nodes(ptr, world, cost)
+        per = np.array([cost[lo:hi].sum() for lo, hi in sh])
+        assert per.max() / per.mean() <= 1.1, (world, per / per.mean())
+        slot, S, sh2 = D.slot_map(ptr, oute, g.E, world, cost)
+        assert sh2 == sh and len(set(slot.tolist())) == g.E
+    sh_e = D.shard_nodes(ptr, 8)
+    per_e = np.array([cost[lo:hi].sum() for lo, hi in sh_e])
+    assert per_e.max() / per_e.mean() > per.max() / per.mean()
+
+
+@pytest.mark.gpu
+def test_allgather_slots_through_the_c_abi_rccl_world1():
+    """The in-library exchange step (mpbp_allgather_slots: in-place ncclAllGather of the slab + bond table on the
+    context's stream) with a one-rank RCCL communicator created through the RCCL library of this process."""
+    import ctypes as C
+    import glob
+    import networkx as nx
+    import torch
+    import mpbp_amd as M
+    torch.cuda.init()
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    rccl = C.CDLL(cands[0], mode=C.RTLD_GLOBAL)
+
+    class UID(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UID()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    N, T, Mb = 8, 4, 4
+    g = M.IndexedBiDiGraph(nx.to_numpy_array(nx.random_regular_graph(3, N, seed=0), nodelist=range(N)))
+    phi = [[np.array([0.9, 0.1]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    bp = M.mpbp(g, [[M.SISFactor(0.1, 0.05)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    M.onebpiter(bp, np.arange(N, dtype=np.int32), M.TruncBond(Mb))
+    before = bp.get_messages()
+    L = bp._L
+    assert L.mpbp_allgather_slots(bp._h, comm, 0, 1, g.E) == 0
+    after = bp.get_messages()
+    for ma, mb in zip(before, after):
+        for a, b in zip(ma, mb):
+            assert np.array_equal(a, b)
+    assert L.mpbp_allgather_slots(bp._h, comm, 0, 2, g.E) == -1          # world * slots_per_rank must equal n_slots
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)

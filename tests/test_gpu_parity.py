@@ -203,6 +203,85 @@ def test_full_size_config2_properties():
     assert abs(M.bethe_free_energy(bp)) < 1e-2 * N
 
 
+def _check_node_properties(bp, nodes, Mb, st):
+    assert st.nan_flag == 0 and st.capacity_flag == 0 and st.jacobi_not_converged == 0
+    b = np.array(M.beliefs(bp))[nodes]
+    assert np.isfinite(b).all() and (b >= -1e-12).all() and np.abs(b.sum(axis=2) - 1).max() < 1e-12
+    bonds = bp.bonds()
+    assert bonds.max() == Mb and (bonds[:, 0] == 1).all() and (bonds[:, -1] == 1).all()
+    return b
+
+
+def test_full_size_config3_glauber_er_properties():
+    """BASELINE configs[2] at its stated dimensions (homogeneous Glauber J=0.5, h=0, beta=1 on
+    networkx.gnp_random_graph(2048, 4/2047, seed=0), T=100, TruncBond(30); glauber_bp.jl:22-44,128-131): two sweeps
+    over all nodes bring every message to the bond cap, then one saturated update (product bond 900, Y_t up to
+    900 (z+1) 2 rows) of a node set holding the highest-degree node; size-independent properties."""
+    N, T, Mb = 2048, 100, 30
+    G = nx.gnp_random_graph(N, 4 / (N - 1), seed=0)
+    A = nx.to_numpy_array(G, nodelist=range(N))
+    m0 = -0.6
+    phi = [[np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    gl = M.Glauber(M.Ising(0.5 * A, np.zeros(N), 1.0), T, phi=phi)
+    bp = gl.mpbp(max_bond=Mb)
+    deg = A.sum(axis=0).astype(int)
+    assert (deg == 0).any() and deg.max() >= 9            # isolated nodes and a long cavity chain are part of the config
+    allnodes = np.arange(N, dtype=np.int32)
+    for _ in range(2):
+        M.onebpiter(bp, allnodes, M.TruncBond(Mb))
+    hub = int(np.argmax(deg))
+    sub = np.array(sorted({hub} | {int(i) for i in np.nonzero(deg == 4)[0][:6]} | {int(np.nonzero(deg == 0)[0][0])}), dtype=np.int32)
+    M.onebpiter(bp, sub, M.TruncBond(Mb))
+    st = bp.last_stats
+    b = _check_node_properties(bp, sub, Mb, st)
+    assert np.abs(b[:, 0, 0] - (1 + m0) / 2).max() < 1e-6      # time-0 marginal = prior
+    assert np.isfinite(M.bethe_free_energy(bp))
+
+
+def test_full_size_config4_karate_properties():
+    """BASELINE configs[3] at its stated dimensions (SIS lambda=0.1 rho=0.05 on notebooks/karate.txt, node 0 infected at
+    t=0, T=200, TruncBond(40)): two sweeps over the graph saturate the bonds, then the two hubs (degrees 16 and 17:
+    cavity chains of 46 / 49 products of bond 40 x 40 = 1600, Y_t = 6400 x 1600) and two leaves are updated."""
+    A = _karate()
+    N, T, Mb = 34, 200, 40
+    phi = [[np.array([0.0, 1.0]) if (t == 0 and i == 0) else (np.array([1.0, 0.0]) if t == 0 else np.ones(2))
+            for t in range(T + 1)] for i in range(N)]
+    g = M.IndexedBiDiGraph(A)
+    bp = M.mpbp(g, [[M.SISFactor(0.1, 0.05)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    for _ in range(2):
+        M.onebpiter(bp, np.arange(N, dtype=np.int32), M.TruncBond(Mb))
+    sub = np.array([0, 11, 26, 33], dtype=np.int32)
+    M.onebpiter(bp, sub, M.TruncBond(Mb))
+    st = bp.last_stats
+    b = _check_node_properties(bp, sub, Mb, st)
+    assert abs(b[0, 0, 1] - 1.0) < 1e-9 and np.abs(b[1:, 0, 1]).max() < 1e-9     # observed initial states
+    pb = np.array(M.pair_beliefs(bp)[0])
+    assert np.abs(pb.sum(axis=(2, 3)) - 1).max() < 1e-10
+    assert np.abs(pb - np.transpose(pb[g.rev], (0, 1, 3, 2))).max() < 1e-9
+
+
+def test_full_size_config5_infinite_graph_properties():
+    """BASELINE configs[4] at its stated dimensions (src/infinite_graph.jl:8-43: k=3 copies of one message, SIS
+    lambda=0.1 rho=0.2, gamma=0.1, T=200, TruncBond(64)): four in-place iterations - bonds 2, 8, 64 and then one
+    iteration with every product at bond 64 x 64 = 4096 (Y_t = 16384 x 4096, 537 MB per time step)."""
+    T, Mb, gam = 200, 64, 0.1
+    phi = [np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)]
+    bp = M.mpbp_infinite_graph(3, [M.SISFactor(0.1, 0.2)] * (T + 1), 2, phi, max_bond=Mb)
+    prev = None
+    for it in range(4):
+        M.onebpiter(bp, [0], M.TruncBond(Mb))
+        st = bp.last_stats
+        assert st.nan_flag == 0 and st.capacity_flag == 0 and st.jacobi_not_converged == 0
+        b = np.array(M.beliefs(bp)[0])
+        assert np.isfinite(b).all() and np.abs(b.sum(axis=1) - 1).max() < 1e-12
+        assert abs(b[0, 1] - gam) < 1e-6
+        if prev is not None:
+            assert np.abs(b - prev).max() < 0.2           # iterations move towards the fixed point, no blow-up
+        prev = b
+    assert bp.bonds().max() == Mb
+    assert np.isfinite(M.bethe_free_energy(bp))
+
+
 def _karate():
     import os
     p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "karate.txt")
@@ -402,6 +481,32 @@ def test_autocorrelations_match_enumeration():
     # the belief train is normalised and reproduces the marginals
     tr = M.belief_train(bp, 0)
     assert tr[0].shape[0] == 1 and tr[-1].shape[1] == 1
+
+
+def test_twovar_marginals_on_device_match_oracle_scan():
+    """mpbp_twovar_marginals (tv_env_kernel / tv_kernel: TensorTrains `twovar_marginals` of the belief trains on the
+    device, reference src/mpbp.jl:239-255) against the oracle's scan of the same trains, with and without maxdist, on a
+    loopy graph with binding truncation (belief bonds up to q * max_bond)."""
+    N, T, Mb = 8, 7, 5
+    lam, rho, gam = 0.2, 0.1, 0.15
+    A, phi = _loopy(N, T, lam, rho, gam)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    M.iterate(bp, maxiter=3, svd_trunc=M.TruncBond(Mb), tol=0.0)
+    for maxdist in (None, 3):
+        tu = M.beliefs_tu(bp, sites=[0, 3, 7], maxdist=maxdist)
+        for k, i in enumerate([0, 3, 7]):
+            ref = OT.twovar_marginals(OT.TensorTrain(M.belief_train(bp, i)), maxdist=maxdist)
+            for t in range(T + 1):
+                for u in range(T + 1):
+                    if ref[t][u] is None:
+                        assert tu[k][t][u] is None
+                    else:
+                        assert np.abs(tu[k][t][u] - ref[t][u]).max() < 1e-12, (i, t, u)
+                        assert abs(tu[k][t][u].sum() - 1) < 1e-12
+    # consistency with the one-time marginals
+    b = M.beliefs(bp)
+    tu = M.beliefs_tu(bp, sites=[2])[0]
+    assert np.abs(tu[1][5].sum(axis=1) - b[2][1]).max() < 1e-10 and np.abs(tu[1][5].sum(axis=0) - b[2][5]).max() < 1e-10
 
 
 @pytest.mark.parametrize("case", ["path3_plus_isolated_T1", "path3_plus_isolated_T5", "single_edge", "hub6"])
