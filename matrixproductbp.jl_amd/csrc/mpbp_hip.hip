@@ -443,6 +443,25 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return pl.cost[a] > pl.cost[b]; });
   std::vector<EngProb> sorted(nprob);
   for (int i = 0; i < nprob; i++) sorted[i] = pl.probs[idx[i]];
+  // The plan's capacities are upper bounds (max_bond); what the operands actually hold is on the device.  One small
+  // copy of their bond tables lets the launch be sized by the real dimensions: during the first sweeps (bonds 1, 2, 4,
+  // ...) a "large" level is really a batch of small problems, and slots sized by max_bond^4 would be wasted.
+  std::vector<int32_t> hb;
+  {
+    int rc = v2_gather_bonds(c, sorted.data(), nprob, hb);
+    if (rc != MPBP_OK) return rc;
+  }
+  int a1 = 1, a2 = 1; int64_t bmact = 1;
+  {
+    const int L1 = c->L + 1;
+    for (int i = 0; i < nprob; i++) {
+      const int32_t* b1 = hb.data() + (size_t)i * 2 * L1; const int32_t* b2 = b1 + L1;
+      for (int t = 0; t < L1; t++) { a1 = std::max(a1, (int)b1[t]); a2 = std::max(a2, (int)b2[t]); bmact = std::max<int64_t>(bmact, (int64_t)b1[t] * b2[t]); }
+    }
+    pl.cap1 = std::min(pl.cap1, a1); pl.cap2 = std::min(pl.cap2, a2);
+  }
+  static const bool no_small = [] { const char* e = getenv("MPBP_DEBUG_NO_SMALL"); return e && e[0] == '1'; }();
+  if (!pl.small && !no_small && (int64_t)pl.cap1 * pl.cap2 * pl.ny * pl.q <= v64::wg::QR_RS * 64 && nprob > 2 * c->num_cu) pl.small = true;
   // few single-wave problems (at most two rounds of 512-thread workgroups): the 512-thread engine finishes them
   // sooner, a single wave per problem only pays off when there are enough problems to fill 4 of them per CU
   // (MPBP_DEBUG_FORCE_SMALL=1 keeps them on the single-wave engine so that small tests cover it)
@@ -456,7 +475,7 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
     const char* gm = getenv("MPBP_GAUGE");
     if (gm && !strcmp(gm, "grid")) grid = true;
     else if (gm && !strcmp(gm, "wg")) grid = false;
-    else grid = Bm * pl.ny * pl.q > 2048 || Bm * Bm * (c->L + 1) * 8 > (int64_t)256 << 20;
+    else grid = bmact * pl.ny * pl.q > 2048 || Bm * Bm * (c->L + 1) * 8 > (int64_t)256 << 20;
     for (const EngProb& P : sorted) if (P.mirror) grid = false;
   }
   pl.ext = grid;
@@ -502,7 +521,7 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   } else {
     for (int done = 0; done < nprob;) {
       int nd = 0;
-      int rc = v2_gauge_sweep(c, sorted.data() + done, nprob - done, &nd);
+      int rc = v2_gauge_sweep(c, sorted.data() + done, nprob - done, hb.data() + (size_t)done * 2 * (c->L + 1), &nd);
       if (rc != MPBP_OK) return rc;
       rc = run(sorted.data() + done, nd);
       if (rc != MPBP_OK) return rc;

@@ -7,4 +7,8 @@
 // launches on c->stream.  Processes the longest prefix whose buffers fit device memory (*n_done, >= 1 on success) and
 // sets probs[i].lf / lfoff / rdim (pointers into c->v2arena, valid until the next call).  Problems must not be
 // mirrored.  Asynchronous: the caller may enqueue sweep 2 on the same stream right away.
-int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, int* n_done);
+// `hb`: host copy of the operands' bond tables, [n][2][L+1] (v2_gather_bonds).
+int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n_done);
+
+// Bond tables (bond1, bond2; L+1 entries each) of probs[0 .. n) -> host, [n][2][L+1].  Synchronises the stream.
+int v2_gather_bonds(mpbp_ctx* c, const EngProb* probs, int n, std::vector<int32_t>& hb);

@@ -25,48 +25,73 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
              bool force_tall) {
   const int P = (int)dims.size();
   if (P == 0) return 0;
-  int kmax_max = 0, rows32_max = 0, cols_max = 0;
-  for (const QrDims& d : dims) { kmax_max = std::max(kmax_max, d.kmax); rows32_max = std::max(rows32_max, r32i(d.rows)); cols_max = std::max(cols_max, d.cols); }
+  int kmax_max = 0, kmax_min = 1 << 30, rows32_max = 0, cols_max = 0;
+  for (const QrDims& d : dims) {
+    kmax_max = std::max(kmax_max, d.kmax); kmax_min = std::min(kmax_min, d.kmax);
+    rows32_max = std::max(rows32_max, r32i(d.rows)); cols_max = std::max(cols_max, d.cols);
+  }
   const int nchunk = (rows32_max + v2::CH - 1) / v2::CH;
   if (nchunk > lay.nchunk) return -1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)v2::k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2::fpanel_lds_bytes(3));
+    attr_done = true;
+  }
   for (int jb = 0; jb < kmax_max; jb += 64) {
     const int npmax = std::min(4, (kmax_max - jb + 15) / 16);
+    // register panels / one workgroup per problem for the in-block updates while the rows below the diagonal fit
+    const bool tall = force_tall || rows32_max - jb > v2::CH;
     for (int p = 0; p < npmax; p++) {
       const int jp = jb + 16 * p;
       if (p > 0) {
-        const dim3 g(1, nchunk, P);
-        switch (p) {
-          case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1);
-                  hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1); break;
-          case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1);
-                  hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1); break;
-          default: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1);
-                   hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1); break;
+        if (!tall) {
+          switch (p) {
+            case 1: hipLaunchKernelGGL(v2::k_inblock<1>, dim3(P), dim3(512), 0, st, d_probs, lay, jb); break;
+            case 2: hipLaunchKernelGGL(v2::k_inblock<2>, dim3(P), dim3(512), 0, st, d_probs, lay, jb); break;
+            default: hipLaunchKernelGGL(v2::k_inblock<3>, dim3(P), dim3(512), 0, st, d_probs, lay, jb); break;
+          }
+        } else {
+          const dim3 g(1, nchunk, P);
+          switch (p) {
+            case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0);
+                    hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0); break;
+            case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0);
+                    hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0); break;
+            default: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0);
+                     hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0); break;
+          }
         }
       }
-      const bool tall = force_tall || rows32_max - jp > v2::CH;
       if (tall) {
         for (int jj = 0; jj <= 16; jj++)
           hipLaunchKernelGGL(v2::k_colstep, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jp, jj, p);
+        hipLaunchKernelGGL(v2::k_gram, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jb, p);
+        hipLaunchKernelGGL(v2::k_build_T, dim3(P), dim3(64), 0, st, d_probs, lay, jb, p);
       } else {
-        hipLaunchKernelGGL(v2::k_fpanel, dim3(P), dim3(512), 0, st, d_probs, lay, jp, p);
+        hipLaunchKernelGGL(v2::k_fpanel, dim3(P), dim3(512), v2::fpanel_lds_bytes(p), st, d_probs, lay, jb, p);
       }
-      hipLaunchKernelGGL(v2::k_gram, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jb, p);
-      hipLaunchKernelGGL(v2::k_build_T, dim3(P), dim3(64), 0, st, d_probs, lay, jb, p);
     }
     const int c0min = jb + 16;     // a problem with one panel left starts its trailing tiles here
     const int ntile_max = cols_max > c0min ? (cols_max - c0min + 15) / 16 : 0;
     if (ntile_max > 0) {
-      const dim3 g((ntile_max + 3) / 4, nchunk, P);
-      switch (npmax) {
-        case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4);
-                hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4); break;
-        case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4);
-                hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4); break;
-        case 3: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4);
-                hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4); break;
-        default: hipLaunchKernelGGL(v2::k_trailW<4>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4);
-                 hipLaunchKernelGGL(v2::k_trailU<4>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4); break;
+      // Many problems: one wave per tile pair over all rows (fused, the tuned wg::qr_trail4); few: tiles x row chunks
+      // over the grid in two launches.  Problems with fewer than four panels left always take the second form.
+      const int ntile4 = cols_max > jb + 64 ? (cols_max - jb - 64 + 15) / 16 : 0;
+      const bool fused = npmax == 4 && ntile4 > 0 && (int64_t)P * ((ntile4 + 1) / 2) >= 1024 && !getenv("MPBP_DEBUG_NO_FUSED_TRAIL");
+      if (fused) hipLaunchKernelGGL(v2::k_trail4f, dim3((ntile4 + 7) / 8, P), dim3(256), 0, st, d_probs, lay, jb);
+      const int only_short = fused ? 1 : 0;
+      if (!fused || kmax_min - jb < 64) {
+        const dim3 g((ntile_max + 3) / 4, nchunk, P);
+        switch (npmax) {
+          case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);
+                  hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short); break;
+          case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);
+                  hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short); break;
+          case 3: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);
+                  hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short); break;
+          default: hipLaunchKernelGGL(v2::k_trailW<4>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);
+                   hipLaunchKernelGGL(v2::k_trailU<4>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short); break;
+        }
       }
     }
   }
@@ -144,34 +169,37 @@ inline v2::Map2 lin(int64_t s) { return v2::Map2{1 << 30, s, 0}; }
 
 }  // namespace
 
-int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, int* n_done) {
+int v2_gather_bonds(mpbp_ctx* c, const EngProb* probs, int n, std::vector<int32_t>& hb) {
+  const int L = c->L;
+  hipStream_t st = c->stream;
+  hb.resize((size_t)n * 2 * (L + 1));
+  if (n <= 0) return MPBP_OK;
+  std::vector<v2::BondSrc> src(n);
+  for (int i = 0; i < n; i++) src[i] = v2::BondSrc{probs[i].bond1, probs[i].bond2};
+  const size_t bsrc = (sizeof(v2::BondSrc) * n + 255) & ~size_t(255), bout = sizeof(int32_t) * hb.size();
+  int rc = ensure_arena(c, c->v2arena, bsrc + bout + 4096);
+  if (rc != MPBP_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->v2arena.base, src.data(), sizeof(v2::BondSrc) * n, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(v2::k_gather_bonds, dim3(n), dim3(64), 0, st, (const v2::BondSrc*)c->v2arena.base, (int32_t*)(c->v2arena.base + bsrc), L);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(hb.data(), c->v2arena.base + bsrc, bout, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return MPBP_OK;
+}
+
+int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n_done) {
   *n_done = 0;
   if (n <= 0) return MPBP_OK;
   const int L = c->L;
   hipStream_t st = c->stream;
-  // ---- bond tables of the operands (produced on the device by earlier launches) -> host
-  std::vector<int32_t> hb((size_t)n * 2 * (L + 1));
-  {
-    std::vector<v2::BondSrc> src(n);
-    for (int i = 0; i < n; i++) {
-      if (probs[i].mirror) return c->fail(MPBP_EINVAL, "internal: mirrored problem in the batched gauge sweep");
-      src[i] = v2::BondSrc{probs[i].bond1, probs[i].bond2};
-    }
-    const size_t bsrc = (sizeof(v2::BondSrc) * n + 255) & ~size_t(255), bout = sizeof(int32_t) * hb.size();
-    int rc = ensure_arena(c, c->v2arena, bsrc + bout + 4096);
-    if (rc != MPBP_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->v2arena.base, src.data(), sizeof(v2::BondSrc) * n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(v2::k_gather_bonds, dim3(n), dim3(64), 0, st, (const v2::BondSrc*)c->v2arena.base, (int32_t*)(c->v2arena.base + bsrc), L);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(hb.data(), c->v2arena.base + bsrc, bout, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-  }
+  for (int i = 0; i < n; i++)
+    if (probs[i].mirror) return c->fail(MPBP_EINVAL, "internal: mirrored problem in the batched gauge sweep");
   // ---- dimensions of every time step (host: they follow from the bond tables)
   std::vector<ProbPlan> plan(n);
   for (int i = 0; i < n; i++) {
     const EngProb& P = probs[i];
     ProbPlan& pp = plan[i];
-    const int32_t* b1 = hb.data() + (size_t)i * 2 * (L + 1);
+    const int32_t* b1 = hb + (size_t)i * 2 * (L + 1);
     const int32_t* b2 = b1 + (L + 1);
     pp.st.resize(L); pp.lfoff.assign(L + 1, 0); pp.rdim.assign(L + 1, 1);
     int64_t off = 0;

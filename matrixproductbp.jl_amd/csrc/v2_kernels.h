@@ -180,18 +180,169 @@ __global__ void __launch_bounds__(512) k_colstep(const QrProb* probs, AuxLay lay
 // Register-resident panel (rows below the diagonal <= 2048): the whole 16-column factorisation in ONE launch.
 // grid (nprob), 512 threads.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) k_fpanel(const QrProb* probs, AuxLay lay, int jp, int pidx) {
+__global__ void __launch_bounds__(512) k_fpanel(const QrProb* probs, AuxLay lay, int jb, int pidx) {
   const QrProb P = probs[blockIdx.x];
+  const int jp = jb + 16 * pidx;
   if (jp >= P.kmax) return;
-  __shared__ double lds_[2 * 8 * 16 + 16 + 64 + 32];
-  ldbl* red = (ldbl*)lds_;
-  ldbl* tau = red + 2 * 8 * 16;
-  ldbl* bc = tau + 16;
+  extern __shared__ __attribute__((aligned(16))) double dyn_[];
+  ldbl* red = (ldbl*)dyn_;                 // [2][8*16]
+  ldbl* tau = red + 2 * 8 * 16;            // [16]
+  ldbl* bc = tau + 16;                     // [96]
+  ldbl* Ts = bc + 96;                      // [256]
+  ldbl* big = Ts + 256;                    // [8 * 256 * (pidx + 1)]
+  const int tid = threadIdx.x;
+  gdbl* Y = (gdbl*)P.Y;
+  gdbl* aux = (gdbl*)P.aux;
   const int rows32 = (P.rows + 31) & ~31;
-  if (threadIdx.x < 16) tau[threadIdx.x] = 0.0;
+  if (tid < 16) tau[tid] = 0.0;
   __syncthreads();
-  qr_panel_regs((gdbl*)P.Y, P.ld, rows32, jp, 16, red, tau, bc);
-  if (threadIdx.x < 16) ((gdbl*)P.aux)[lay.tau + pidx * 16 + threadIdx.x] = tau[threadIdx.x];
+  qr_panel_regs(Y, P.ld, rows32, jp, 16, red, tau, bc);
+  // Gram of the new panel with itself and with the earlier panels of its block, T from the Gram (one pass over the rows)
+  switch (pidx) {
+    case 0: { const int jy[1] = {jp}; qr_gramN<1>(Y, P.ld, rows32, jp, jp, jy, big); break; }
+    case 1: { const int jy[2] = {jp, jb}; qr_gramN<2>(Y, P.ld, rows32, jp, jp, jy, big); break; }
+    case 2: { const int jy[3] = {jp, jb, jb + 16}; qr_gramN<3>(Y, P.ld, rows32, jp, jp, jy, big); break; }
+    default: { const int jy[4] = {jp, jb, jb + 16, jb + 32}; qr_gramN<4>(Y, P.ld, rows32, jp, jp, jy, big); break; }
+  }
+  for (int k = 1; k <= pidx; k++)
+    for (int i = tid; i < 256; i += 512) aux[lay.S + (long)(pidx * (pidx - 1) / 2 + (k - 1)) * 256 + i] = big[256 * k + i];
+  qr_T_from_gram(big, tau, 16, Ts);
+  for (int i = tid; i < 256; i += 512) aux[lay.T + pidx * 256 + i] = Ts[i];
+  if (tid < 16) aux[lay.tau + pidx * 16 + tid] = tau[tid];
+}
+constexpr int FPANEL_LDS_BASE = 2 * 8 * 16 + 16 + 96 + 256;
+__host__ __device__ inline size_t fpanel_lds_bytes(int pidx) { return sizeof(double) * (FPANEL_LDS_BASE + 8 * 256 * (pidx + 1)); }
+
+// Left-looking update inside a block for problems whose rows fit one workgroup's pass (any number of rows works; the
+// launch is used while the rows below the diagonal are <= CH): tile = panel NP of the block at jb, updated by panels
+// 0 .. NP-1; the eight waves share the rows, partial products through LDS.  grid (nprob), 512 threads.
+template <int NP>
+__global__ void __launch_bounds__(512) k_inblock(const QrProb* probs, AuxLay lay, int jb) {
+  const QrProb P = probs[blockIdx.x];
+  const int cb0 = jb + 16 * NP;
+  if (cb0 >= P.kmax) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  gdbl* Y = (gdbl*)P.Y;
+  const gdbl* aux = (const gdbl*)P.aux;
+  const long ld = P.ld;
+  const int rows32 = (P.rows + 31) & ~31;
+  constexpr int NS = NP * (NP - 1) / 2;
+  __shared__ double sh_[(NP + NS + 8 * NP) * 256];
+  ldbl* Tq = (ldbl*)sh_;
+  ldbl* Sq = Tq + NP * 256;
+  ldbl* big = Sq + NS * 256;
+  for (int i = tid; i < NP * 256; i += 512) Tq[i] = aux[lay.T + i];
+  for (int i = tid; i < (NP * (NP - 1) / 2) * 256; i += 512) Sq[i] = aux[lay.S + i];
+  d4 acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) acc[p] = d4{0, 0, 0, 0};
+  const int nrb = (rows32 - jb) >> 4;
+  for (int rb = wave; rb < nrb; rb += 8) {
+    const int row0 = jb + 16 * rb + 4 * g;
+    const d4 c = *reinterpret_cast<const gd4*>(Y + (long)(cb0 + l15) * ld + row0);
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      d4 v = *reinterpret_cast<const gd4*>(Y + (long)(jb + 16 * p + l15) * ld + row0);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int rr = 16 * (rb - p) + 4 * g + e;
+        double a = v[e];
+        a = (rr < 16) ? ((rr > l15) ? a : ((rr == l15) ? 1.0 : 0.0)) : a;
+        v[e] = (rr >= 0) ? a : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[p] = mfma(v[e], c[e], acc[p]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; p++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) big[(wave * NP + p) * 256 + (g + 4 * r) + 16 * l15] = acc[p][r];
+  __syncthreads();
+  d4 w[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    d4 t = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int w2 = 0; w2 < 8; w2++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) t[r] += big[(w2 * NP + p) * 256 + (g + 4 * r) + 16 * l15];
+#pragma unroll
+    for (int r = 0; r < NP; r++) {
+      if (r < p) {
+        const ldbl* S = Sq + (p * (p - 1) / 2 + r) * 256;
+#pragma unroll
+        for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][s], t);
+      }
+    }
+    d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) o = mfma(Tq[p * 256 + (4 * s + g) + 16 * l15], t[s], o);
+    w[p] = o;
+  }
+  const int jb32 = jb & ~31;
+  const int nst = (rows32 - jb32) >> 5;
+  for (int st = wave; st < nst; st += 8) {
+    const int row = jb32 + 32 * st + 2 * l15;
+    d2 v[NP][4];
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        const int k = 4 * s2 + g;
+        d2 x = *reinterpret_cast<const gd2*>(Y + (long)(jb + 16 * p + k) * ld + row);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int rp = row + e - jb - 16 * p;
+          double a = x[e];
+          a = (rp < 16) ? ((rp > k) ? a : ((rp == k) ? 1.0 : 0.0)) : a;
+          x[e] = (rp >= 0) ? a : 0.0;
+        }
+        v[p][s2] = x;
+      }
+    d2 c[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      d4 a4 = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+        for (int p = 0; p < NP; p++) a4 = mfma(-w[p][s2], v[p][s2][e], a4);
+#pragma unroll
+      for (int r = 0; r < 4; r++) c[r][e] = a4[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) *reinterpret_cast<gd2*>(Y + (long)(cb0 + g + 4 * r) * ld + row) = c[r];
+  }
+}
+
+// Trailing update by the four panels of the block at jb for problems that have all four (np == 4): every wave takes a
+// pair of 16-column tiles over ALL rows (wg::qr_trail4: phases A, B, C in registers, the V fragments of a row block
+// shared by both tiles).  For batches of many problems - one wave per tile pair is only enough parallelism then.
+// grid (ceil(tile pairs / 4), nprob), 256 threads.
+__global__ void __launch_bounds__(256) k_trail4f(const QrProb* probs, AuxLay lay, int jb) {
+  const QrProb P = probs[blockIdx.y];
+  if (P.kmax - jb < 64) return;                       // fewer than four panels left: k_trailW / k_trailU<NP> take it
+  const int c0 = jb + 64;
+  const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
+  if (blockIdx.x * 8 >= ntile) return;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const gdbl* aux = (const gdbl*)P.aux;
+  __shared__ double ts_[10 * 256];
+  ldbl* T0 = (ldbl*)ts_;
+  for (int i = tid; i < 4 * 256; i += 256) T0[i] = aux[lay.T + i];
+  for (int i = tid; i < 6 * 256; i += 256) T0[1024 + i] = aux[lay.S + i];
+  __syncthreads();
+  const ldbl* const Tq[4] = {T0, T0 + 256, T0 + 512, T0 + 768};
+  const ldbl* const Sq[6] = {T0 + 1024, T0 + 1280, T0 + 1536, T0 + 1792, T0 + 2048, T0 + 2304};
+  const int tile = (blockIdx.x * 4 + wave) * 2;
+  if (tile >= ntile) return;
+  const int rows32 = (P.rows + 31) & ~31;
+  if (tile + 1 < ntile) qr_trail4<2>((gdbl*)P.Y, P.ld, rows32, jb, c0 + 16 * tile, Tq, Sq);
+  else qr_trail4<1>((gdbl*)P.Y, P.ld, rows32, jb, c0 + 16 * tile, Tq, Sq);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -307,9 +458,10 @@ __device__ __forceinline__ TrailGeom trail_geom(const QrProb& P, int jb, int NP,
 }
 
 template <int NP>
-__global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw) {
+__global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw, int only_short) {
   const QrProb P = probs[blockIdx.z];
   if (jb >= P.kmax) return;
+  if (only_short && P.kmax - jb >= 64) return;        // k_trail4f has taken the problems with four panels
   const TrailGeom G = trail_geom(P, jb, NP, inblock != 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, l15 = lane & 15;
@@ -356,9 +508,10 @@ __global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay,
 }
 
 template <int NP>
-__global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw) {
+__global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw, int only_short) {
   const QrProb P = probs[blockIdx.z];
   if (jb >= P.kmax) return;
+  if (only_short && P.kmax - jb >= 64) return;
   const TrailGeom G = trail_geom(P, jb, NP, inblock != 0);
   if (G.ntile == 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
