@@ -139,6 +139,7 @@ int mpbp_set_psi(mpbp_ctx* ctx, const double* psi);
  *   data: for each edge, cores in time order, each core column-major [b_t, b_{t+1}, q, q];
  *   offsets[e] = index in `data` (in doubles) of edge e's first core.
  * The messages must be normalised (z = 1), as `bp.μ` always is after set_msg!.
+ * offsets[e] < 0 keeps edge e's current message (partial upload).
  */
 int mpbp_set_messages(mpbp_ctx* ctx, const int32_t* bonds, const int64_t* offsets, const double* data);
 int mpbp_get_bonds(mpbp_ctx* ctx, int32_t* bonds /* [n_edges*(T+2)] */);

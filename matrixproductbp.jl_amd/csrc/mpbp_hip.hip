@@ -174,6 +174,7 @@ extern "C" int mpbp_set_messages(mpbp_ctx* c, const int32_t* bonds, const int64_
   const int L = c->L, qq = c->q * c->q;
   std::vector<double> slot((size_t)c->slot_doubles);
   for (int e = 0; e < c->E; e++) {
+    if (offsets[e] < 0) continue;      // negative offset: keep this edge's message (partial upload)
     const int32_t* b = bonds + (int64_t)e * (L + 1);
     if (b[0] != 1 || b[L] != 1) return c->fail(MPBP_EINVAL, "edge %d: open-chain messages need bond 1 at both ends", e);
     const double* src = data + offsets[e];

@@ -78,7 +78,11 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       // over the grid in two launches.  Problems with fewer than four panels left always take the second form.
       const int ntile4 = cols_max > jb + 64 ? (cols_max - jb - 64 + 15) / 16 : 0;
       const bool fused = npmax == 4 && ntile4 > 0 && (int64_t)P * ((ntile4 + 1) / 2) >= 1024 && !getenv("MPBP_DEBUG_NO_FUSED_TRAIL");
-      if (fused) hipLaunchKernelGGL(v2::k_trail4f, dim3((ntile4 + 7) / 8, P), dim3(256), 0, st, d_probs, lay, jb);
+      static const int trail_nt = [] { const char* e = getenv("MPBP_TRAIL_NT"); return e ? atoi(e) : 2; }();
+      if (fused) {
+        if (trail_nt == 1) hipLaunchKernelGGL(v2::k_trail4f<1>, dim3((ntile4 + 3) / 4, P), dim3(256), 0, st, d_probs, lay, jb);
+        else hipLaunchKernelGGL(v2::k_trail4f<2>, dim3((ntile4 + 7) / 8, P), dim3(256), 0, st, d_probs, lay, jb);
+      }
       const int only_short = fused ? 1 : 0;
       if (!fused || kmax_min - jb < 64) {
         const dim3 g((ntile_max + 3) / 4, nchunk, P);

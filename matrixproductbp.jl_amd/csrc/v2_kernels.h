@@ -323,12 +323,13 @@ __global__ void __launch_bounds__(512) k_inblock(const QrProb* probs, AuxLay lay
 // pair of 16-column tiles over ALL rows (wg::qr_trail4: phases A, B, C in registers, the V fragments of a row block
 // shared by both tiles).  For batches of many problems - one wave per tile pair is only enough parallelism then.
 // grid (ceil(tile pairs / 4), nprob), 256 threads.
-__global__ void __launch_bounds__(256) k_trail4f(const QrProb* probs, AuxLay lay, int jb) {
+template <int NT>
+__global__ void __launch_bounds__(256, NT == 1 ? 3 : 2) k_trail4f(const QrProb* probs, AuxLay lay, int jb) {
   const QrProb P = probs[blockIdx.y];
   if (P.kmax - jb < 64) return;                       // fewer than four panels left: k_trailW / k_trailU<NP> take it
   const int c0 = jb + 64;
   const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
-  if (blockIdx.x * 8 >= ntile) return;
+  if (blockIdx.x * 4 * NT >= ntile) return;
   const int tid = threadIdx.x, wave = tid >> 6;
   const gdbl* aux = (const gdbl*)P.aux;
   __shared__ double ts_[10 * 256];
@@ -338,10 +339,10 @@ __global__ void __launch_bounds__(256) k_trail4f(const QrProb* probs, AuxLay lay
   __syncthreads();
   const ldbl* const Tq[4] = {T0, T0 + 256, T0 + 512, T0 + 768};
   const ldbl* const Sq[6] = {T0 + 1024, T0 + 1280, T0 + 1536, T0 + 1792, T0 + 2048, T0 + 2304};
-  const int tile = (blockIdx.x * 4 + wave) * 2;
+  const int tile = (blockIdx.x * 4 + wave) * NT;
   if (tile >= ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
-  if (tile + 1 < ntile) qr_trail4<2>((gdbl*)P.Y, P.ld, rows32, jb, c0 + 16 * tile, Tq, Sq);
+  if (NT == 2 && tile + 1 < ntile) qr_trail4<2>((gdbl*)P.Y, P.ld, rows32, jb, c0 + 16 * tile, Tq, Sq);
   else qr_trail4<1>((gdbl*)P.Y, P.ld, rows32, jb, c0 + 16 * tile, Tq, Sq);
 }
 

@@ -321,19 +321,41 @@ class MPBP:
         return out
 
     def set_messages(self, msgs):
+        """`bp.μ[e] = msgs[e]` (lists over t of arrays [b_t, b_{t+1}, q, q], normalised); entries that are None keep
+        the message the device holds."""
         q, E, T = self.q, self.g.ne(), self.T
         b = np.ones((E, T + 2), dtype=np.int32)
         chunks, offs, o = [], np.zeros(E, dtype=np.int64), 0
         for e in range(E):
+            if msgs[e] is None:
+                offs[e] = -1
+                continue
             offs[e] = o
             for t in range(T + 1):
                 a = np.asarray(msgs[e][t], dtype=np.float64)
                 b[e, t], b[e, t + 1] = a.shape[0], a.shape[1]
                 chunks.append(a.ravel(order="F"))
                 o += a.size
-        data = np.concatenate(chunks)
+        data = np.concatenate(chunks) if chunks else np.zeros(1)
         _lib.check(self._L.mpbp_set_messages(self._h, _ip(b), offs.ctypes.data_as(C.POINTER(C.c_int64)), _dp(data)),
                    self._h)
+
+
+def random_message(T, q, bond, rng):
+    """A normalised random MPEM2 at the saturated bond profile min(bond, q^2t, q^2(T+1-t)) with positive cores: a
+    stand-in for a converged message when only the DIMENSIONS of the update matter (full-size tests, benchmarks of
+    one saturated sweep without the sweeps that lead there)."""
+    L = T + 1
+    prof = [int(min(bond, float(q * q) ** min(t, L - t, 40))) for t in range(L + 1)]
+    cores = [rng.uniform(0.5, 1.5, size=(prof[t], prof[t + 1], q, q)) / (prof[t + 1] * q * q) for t in range(L)]
+    v, logz = np.ones((1, 1)), 0.0
+    for a in cores:
+        v = v @ a.sum(axis=(2, 3))
+        s = np.abs(v).max()
+        v, logz = v / s, logz + np.log(s)
+    logz += np.log(v[0, 0])
+    f = np.exp(-logz / L)
+    return [a * f for a in cores]
 
 
 def mpbp(g, w, q, T, d=1, phi=None, psi=None, max_bond=None, **kw):
