@@ -51,6 +51,31 @@ def _cpu_model():
     return "unknown"
 
 
+def _host_cores():
+    """CPUs this process may really use: the scheduler affinity, capped by the cgroup CPU quota (a one-GPU box of the
+    pool is a 16-CPU share of a 256-thread host: 256 workers there just time-slice 16 CPUs)."""
+    n = len(os.sched_getaffinity(0))
+    why = "sched_getaffinity"
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            c = max(1, int(round(int(q) / int(per))))
+            if c < n:
+                n, why = c, "cgroup cpu.max"
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and max(1, round(q / per)) < n:
+                n, why = max(1, round(q / per)), "cgroup cfs quota"
+        except (OSError, ValueError):
+            pass
+    env = os.environ.get("MPBP_BENCH_CPU_CORES")
+    if env:
+        n, why = int(env), "MPBP_BENCH_CPU_CORES"
+    return n, why
+
+
 def cpu_baseline(node_msgs, lam, rho, gam, T, Mb, E_per_sweep, n_heavy=64):
     """node_msgs: the incoming messages (lists of cores) of several degree-3 nodes from the device state after the
     warm-up sweeps.  Sample: >= n_heavy heavy `op`s (Kronecker 20x20 -> compress!, 100 SVDs up
@@ -62,7 +87,7 @@ def cpu_baseline(node_msgs, lam, rho, gam, T, Mb, E_per_sweep, n_heavy=64):
     from oracle import mpbp as O
     from oracle.factors import SISFactor
     from oracle.tensor_trains import TensorTrain, TruncBond, compress, normalize, normalize_eachmatrix
-    cores = len(os.sched_getaffinity(0))
+    cores, cores_why = _host_cores()
     wi = [SISFactor(lam, rho)] * (T + 1)
     psi = [np.ones((2, 2))] * (T + 1)
     phi = [np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)]
@@ -100,10 +125,10 @@ def cpu_baseline(node_msgs, lam, rho, gam, T, Mb, E_per_sweep, n_heavy=64):
     t_node = 4 * t_heavy + 3 * t_light + 3 * t_fin + t_bel
     rate = cores * 3.0 / t_node
     return {"value": rate, "unit": "edge-updates/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
-            "nproc": os.cpu_count(), "s_per_sweep": E_per_sweep / rate, "n_heavy_ops_sampled": n_ops,
+            "nproc": os.cpu_count(), "cores_from": cores_why, "s_per_sweep": E_per_sweep / rate, "n_heavy_ops_sampled": n_ops,
             "sample_wall_s": wall,
             "sample": (f"numpy oracle (LAPACK gesdd), {n_ops} heavy ops from the message pairs of {len(node_msgs)} nodes on "
-                       f"{cores} processes (all host cores; mean {t_heavy:.2f} s per op per core, {wall:.0f} s wall) + "
+                       f"{cores} processes (all CPUs this process may use: {cores_why}; mean {t_heavy:.2f} s per op per core, {wall:.0f} s wall) + "
                        f"light op {t_light:.3f} s + finalisation {t_fin:.3f} s + belief {t_bel:.3f} s on the "
                        f"post-warm-up messages; node update = 4 heavy + 3 light + 3 fin + 1 belief "
                        f"= {t_node:.1f} s/core")}

@@ -68,7 +68,7 @@ __device__ inline void atomic_max_double_pos(unsigned long long* addr, double v)
 
 // CORES_LDS / JAC_LDS: whether the staged cores + coupling table / the Jacobi matrix live in LDS or in the slot's
 // HBM scratch (decided per launch by the host, plan_cfg); compile-time so that every access has a known address space.
-template <bool CORES_LDS, bool JAC_LDS>
+template <bool CORES_LDS, bool JAC_LDS, bool EXT>
 __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, double* lds_, EngStats* stats) {
   typedef typename std::conditional<CORES_LDS, ldbl*, gdbl*>::type CP;
   typedef typename std::conditional<JAC_LDS, ldbl*, gdbl*>::type JP;
@@ -106,7 +106,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
   auto LB2 = [&](int t) { return mirror ? Pb2[L - t] : Pb2[t]; };
   auto TP = [&](int t) { return mirror ? (L - 1 - t) : t; };
   // triangular factors: own sweep 1 (slot stack, ranks in LDS) or the batched gauge sweep's (P.lf != null)
-  const bool ext = P.lf != nullptr;
+  constexpr bool ext = EXT;        // compile time: the in-workgroup sweep 1 keeps its code generation
   const gdbl* Plf = (const gdbl*)P.lf;
   const __attribute__((address_space(1))) int64_t* Plfoff = (const __attribute__((address_space(1))) int64_t*)P.lfoff;
   const gint* Prd = (const gint*)P.rdim;

@@ -24,12 +24,22 @@
       const int p = s_p;                                                                                          \
       __syncthreads();                                                                                            \
       if (p >= nprob) break;                                                                                      \
-      if (cfg.lds_A1c >= 0) {                                                                                     \
-        if (cfg.lds_JA >= 0) eng::run_problem<true, true>(probs[p], cfg, slot, lds, stats);                       \
-        else eng::run_problem<true, false>(probs[p], cfg, slot, lds, stats);                                      \
-      } else {                                                                                                    \
-        if (cfg.lds_JA >= 0) eng::run_problem<false, true>(probs[p], cfg, slot, lds, stats);                      \
-        else eng::run_problem<false, false>(probs[p], cfg, slot, lds, stats);                                     \
+      if (probs[p].lf == nullptr) {                                                                               \
+        if (cfg.lds_A1c >= 0) {                                                                                   \
+          if (cfg.lds_JA >= 0) eng::run_problem<true, true, false>(probs[p], cfg, slot, lds, stats);              \
+          else eng::run_problem<true, false, false>(probs[p], cfg, slot, lds, stats);                             \
+        } else {                                                                                                  \
+          if (cfg.lds_JA >= 0) eng::run_problem<false, true, false>(probs[p], cfg, slot, lds, stats);             \
+          else eng::run_problem<false, false, false>(probs[p], cfg, slot, lds, stats);                            \
+        }                                                                                                         \
+      } else {   /* triangular factors from the batched gauge sweep: sweep 2 only */                              \
+        if (cfg.lds_A1c >= 0) {                                                                                   \
+          if (cfg.lds_JA >= 0) eng::run_problem<true, true, true>(probs[p], cfg, slot, lds, stats);               \
+          else eng::run_problem<true, false, true>(probs[p], cfg, slot, lds, stats);                              \
+        } else {                                                                                                  \
+          if (cfg.lds_JA >= 0) eng::run_problem<false, true, true>(probs[p], cfg, slot, lds, stats);              \
+          else eng::run_problem<false, false, true>(probs[p], cfg, slot, lds, stats);                             \
+        }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
   }                                                                                                               \

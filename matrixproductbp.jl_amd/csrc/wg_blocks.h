@@ -345,6 +345,9 @@ constexpr int QR_LDS_BASE = 2 * WG_WAVES * 16 + 16 * 16 + 16 + 2 * 32 + 2 * 16; 
 constexpr int QR_ROWPAR_TILES = 1;   // trailing tiles at or below which a 4-panel update runs row-parallel (one tile at a time)
 constexpr bool QR_QUAD = (WG_THREADS == 512);   // aggregate four panels (K = 64 trailing updates) - 512-thread variant only
 constexpr int QR_LDS_PAIR = QR_LDS_BASE + 256 + 256 + 16;
+#ifndef QR_TRAIL_PER_WAVE
+#define QR_TRAIL_PER_WAVE 0      // 1: every wave streams its own copy of the reflector panels (the round-1 trailing update)
+#endif
 constexpr int QR_LDS_DOUBLES = QR_LDS_PAIR + (QR_QUAD ? 7 * 256 + 32 : 0);
 
 // Cross-lane exchanges without the LDS crossbar (ds_bpermute): gfx950's v_permlane32_swap / v_permlane16_swap do a
@@ -1387,6 +1390,184 @@ __device__ __attribute__((noinline)) void qr_tile_update4_all(gdbl* Y, long ld, 
   __syncthreads();
 }
 
+// Trailing update by the FOUR panels at j0 of ALL tiles [cstart, cstart + 16 ntl) with the reflector panels shared
+// through LDS: the eight waves of the workgroup walk the rows together, 32 at a time; every 32-row stage of the four
+// panels (64 columns, heads already in unit-lower-trapezoidal form) is loaded from HBM ONCE by the whole workgroup and
+// read by every wave as LDS fragments, instead of each wave streaming its own copy of V through the vector L1 (which
+// made phase C L1-bound: 16 KB of V per wave and stage against 16 KB of C).  Every wave owns up to NT = 2 tiles per pass
+// (contiguous runs, as wave_tiles); C goes straight from HBM to registers and back (nontemporal).
+//   Vs: 2 * QR_VS_STAGE doubles of LDS (double buffer).  Column stride QR_VS_LD = 34 rows: == 4 banks (mod 64) per
+//   column, so the phase A reads (16 lanes = 16 columns, 32 B each) and the phase C reads (16 lanes = 32 consecutive
+//   rows of one column) are both conflict free.  One barrier per stage.
+constexpr int QR_VS_LD = 34;
+constexpr int QR_VS_STAGE = 64 * QR_VS_LD;
+typedef __attribute__((address_space(3))) d2 ld2;
+__device__ __attribute__((noinline)) void qr_trail4_coop(gdbl* Y, long ld, int rows32, int j0, int cstart, int ntl,
+                                                         const ldbl* const (&Tq)[4], const ldbl* const (&Sq)[6], ldbl* Vs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nst = (rows32 - j0) >> 5;                     // 32-row stages (j0 is a multiple of 64)
+  // staging map: thread -> (column sc of the 64, rows 4*sr .. 4*sr+3 of the stage)
+  const int sc = tid >> 3, sr = tid & 7;
+  const gdbl* vsrc = Y + (long)(j0 + sc) * ld + j0 + 4 * sr;
+  const int spanel = sc >> 4, scol = sc & 15;
+  auto stage_load = [&](int s) -> d4 {
+    const int sclamp = min(s, nst - 1);
+    return *reinterpret_cast<const gd4*>(vsrc + 32 * sclamp);
+  };
+  auto stage_store = [&](int s, d4 v) {
+    ldbl* dst = Vs + (s & 1) * QR_VS_STAGE + sc * QR_VS_LD + 4 * sr;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rp = 32 * s + 4 * sr + e - 16 * spanel;     // row relative to this panel's diagonal block
+      double a = v[e];
+      a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
+      v[e] = (rp >= 0) ? a : 0.0;
+    }
+    *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
+    *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
+  };
+  // this wave's tiles: contiguous run (as wave_tiles)
+  const int tbase = ntl / WG_WAVES, trem = ntl % WG_WAVES;
+  const int tcnt = tbase + (wave < trem ? 1 : 0);
+  const int tstart = wave * tbase + min(wave, trem);
+  const int npass = (tbase + (trem ? 1 : 0) + 1) >> 1;
+  for (int pass = 0; pass < npass; pass++) {
+    const int t0 = 2 * pass;
+    const int nt = max(0, min(2, tcnt - t0));               // tiles of this wave in this pass (wave-uniform)
+    const int cb0 = cstart + 16 * (tstart + t0);
+    // clamp the column pointers of absent tiles to a valid tile (loaded, never stored)
+    const int cq0 = (nt >= 1) ? cb0 : cstart, cq1 = (nt >= 2) ? cb0 + 16 : cq0;
+    // ------------------------------------------------------------ phase A: W0_p = V_p^T C
+    d4 w0[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; p++) { w0[p][0] = d4{0, 0, 0, 0}; w0[p][1] = d4{0, 0, 0, 0}; }
+    {
+      const gdbl* c0p = Y + (long)(cq0 + l15) * ld + j0 + 4 * g;
+      const gdbl* c1p = Y + (long)(cq1 + l15) * ld + j0 + 4 * g;
+      d4 vreg = stage_load(0);
+      __syncthreads();                                      // the previous users of Vs are done
+      stage_store(0, vreg);
+      d4 cc[2][2];                                          // [tile][row block of the stage], one stage ahead
+      cc[0][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c0p));
+      cc[0][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c0p + 16));
+      cc[1][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c1p));
+      cc[1][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c1p + 16));
+      for (int s = 0; s < nst; s++) {
+        vreg = stage_load(s + 1);
+        const int sn = min(s + 1, nst - 1);
+        d4 cn[2][2];
+        cn[0][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c0p + 32 * sn));
+        cn[0][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c0p + 32 * sn + 16));
+        cn[1][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c1p + 32 * sn));
+        cn[1][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c1p + 32 * sn + 16));
+        lds_barrier();                                      // stage s is in Vs[s & 1]; the prefetches stay in flight
+        const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
+        if (nt > 0) {
+#pragma unroll
+          for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+              const ldbl* vp = vb + (16 * p + l15) * QR_VS_LD + 16 * rb + 4 * g;
+              const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
+              const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
+              if (nt > 1) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]);
+                  w0[p][1] = mfma(v4[e], cc[1][rb][e], w0[p][1]);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]);
+              }
+            }
+          }
+        }
+        stage_store(s + 1, vreg);                           // into the other buffer: nobody reads it before the next barrier
+        cc[0][0] = cn[0][0]; cc[0][1] = cn[0][1]; cc[1][0] = cn[1][0]; cc[1][1] = cn[1][1];
+      }
+    }
+    // ------------------------------------------------------------ phase B: the W recurrence (registers)
+    d4 w[4][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        d4 t = w0[p][q];
+#pragma unroll
+        for (int r = 0; r < p; r++) {
+          const ldbl* S = Sq[p * (p - 1) / 2 + r];
+#pragma unroll
+          for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
+        }
+        d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; s++) o = mfma(Tq[p][(4 * s + g) + 16 * l15], t[s], o);
+        w[p][q] = o;
+      }
+    }
+    // ------------------------------------------------------------ phase C: C^T -= sum_p W_p^T V_p^T
+    {
+      d4 vreg = stage_load(0);
+      __syncthreads();                                      // every wave has left phase A's last stage
+      stage_store(0, vreg);
+      gdbl* cp0 = Y + (long)(cq0 + g) * ld + j0 + 2 * l15;
+      gdbl* cp1 = Y + (long)(cq1 + g) * ld + j0 + 2 * l15;
+      d2 cc[2][4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        cc[0][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp0 + (long)(4 * r) * ld));
+        cc[1][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld));
+      }
+      for (int s = 0; s < nst; s++) {
+        vreg = stage_load(s + 1);
+        const int sn = min(s + 1, nst - 1);
+        d2 cn[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          cn[0][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp0 + (long)(4 * r) * ld + 32 * sn));
+          cn[1][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld + 32 * sn));
+        }
+        lds_barrier();
+        const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
+        if (nt > 0) {
+          d4 acc[2][2];                                     // [tile][e]
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
+#pragma unroll
+          for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) {
+              const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * QR_VS_LD + 2 * l15);
+              if (nt > 1) {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                  acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]);
+                  acc[1][e] = mfma(-w[p][1][s2], v[e], acc[1][e]);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 2; e++) acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]);
+              }
+            }
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            __builtin_nontemporal_store(d2{acc[0][0][r], acc[0][1][r]}, reinterpret_cast<gd2*>(cp0 + (long)(4 * r) * ld + 32 * s));
+            if (nt > 1) __builtin_nontemporal_store(d2{acc[1][0][r], acc[1][1][r]}, reinterpret_cast<gd2*>(cp1 + (long)(4 * r) * ld + 32 * s));
+          }
+        }
+        stage_store(s + 1, vreg);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { cc[0][r] = cn[0][r]; cc[1][r] = cn[1][r]; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // `big`: >= WG_WAVES*1024 doubles of LDS scratch when QR_QUAD (else WG_WAVES*512); may alias the gemm tile buffers
 __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
@@ -1483,6 +1664,9 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
       if (WG_WAVES > 1 && ntl4 <= QR_ROWPAR_TILES) {
         // few tiles left: one tile at a time, rows shared out to all waves
         for (int tl = 0; tl < ntl4; tl++) qr_tile_update4_all(Y, ld, rows32, j0, j0 + 64 + 16 * tl, Tq, Sq, big);
+      } else if (WG_WAVES == 8 && !QR_TRAIL_PER_WAVE) {
+        // reflector panels shared through LDS, all waves in step (see qr_trail4_coop)
+        qr_trail4_coop(Y, ld, rows32, j0, j0 + 64, ntl4, Tq, Sq, big);
       } else {
         int tstart, tcnt;
         wave_tiles(j0 + 64, tstart, tcnt);

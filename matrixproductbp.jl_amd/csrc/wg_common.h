@@ -36,4 +36,14 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only: this wave's LDS operations are complete (lgkmcnt(0)), outstanding
+// global loads stay in flight across it (a __syncthreads() drains vmcnt as well and serialises every prefetch that spans
+// a barrier - cdna_hip_programming.md section 5, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // vmcnt = 63, expcnt = 7, lgkmcnt = 0
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 }  // namespace wgc

@@ -1,0 +1,8 @@
+import ctypes as C, os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import mpbp_amd
+L = mpbp_amd._lib.lib()
+ms = C.c_double(0)
+for nb in (256, 64):
+    L.mpbp_selftest_qr_bench(0, 1600, 400, nb, 3, C.byref(ms))
+    print("nblocks", nb, "ms", ms.value, flush=True)
