@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0,
                     help="with one process: run only rank 0's node block of a K-way sharding (what one GPU of K does per sweep)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="heavy ops timed by the CPU baseline (>= host cores)")
+    ap.add_argument("--saturate", action="store_true",
+                    help="start from random normalised messages at the saturated bond profile on the in-edges of the owned "
+                         "nodes (the dimensions of a converged state without the sweeps that lead there; use with --warmup 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (gloo = rehearsal on one GPU)")
     ap.add_argument("--dump-beliefs", default="", help="write rank-0 beliefs + f to this .npy file (parity checks)")
@@ -239,6 +242,23 @@ def main():
         E, deg, lo, hi, ptr, ine = 3, np.array([3]), 0, 1, [0, 3], None
         cores_t = bonds_t = None
     exchange = shardable and world > 1
+    if args.saturate and A is not None:
+        rng = np.random.default_rng(1234 + rank)
+        msgs = [None] * E
+        for i in range(lo, hi):
+            for p_ in range(int(ptr[i]), int(ptr[i + 1])):
+                msgs[int(ine[p_])] = M.random_message(T, 2, Mb, rng)
+        bp.set_messages(msgs)
+        del msgs
+    # heartbeat on stderr: a long silent run looks hung to the job runner
+    import threading
+    t_start = time.time()
+
+    def _beat():
+        while True:
+            time.sleep(60)
+            print(f"[bench] running, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
+    threading.Thread(target=_beat, daemon=True).start()
     bp._L.mpbp_set_profiling(bp._h, 2 if args.phase_profile else 1)
     owned = np.arange(lo, hi, dtype=np.int32)
     trunc = M.TruncBond(Mb)

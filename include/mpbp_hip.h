@@ -156,6 +156,10 @@ int mpbp_reset_messages(mpbp_ctx* ctx);
  * Writes the outgoing messages of the listed nodes, their belief marginals and f[i].
  * If an out-edge id occurs more than once for a node (InfiniteRegularGraph) the last occurrence is
  * the one stored, as in the reference's loop (src/recursive_bp_factor.jl:154-159).
+ * Blocking: returns after the context's stream has been synchronised, so the slab may be handed to a collective on
+ * any stream right away (mpbp_allgather_slots, or the caller's own RCCL call).  Node lists whose work trains do not
+ * fit the device are split internally; the pieces read a snapshot of the slab taken at entry, results are those of
+ * one pass.
  */
 int mpbp_sweep(mpbp_ctx* ctx, const int32_t* nodes, int32_t n_nodes, mpbp_trunc trunc, double damp,
                mpbp_stats* stats /* may be NULL */);

@@ -76,7 +76,7 @@ MPBP_ENGINE_KERNEL(__launch_bounds__(512))
 namespace v64 {
 #include "wg_blocks.h"
 #include "engine.h"
-MPBP_ENGINE_KERNEL(__launch_bounds__(64, 2))
+MPBP_ENGINE_KERNEL(__launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))))
 }  // namespace v64
 #undef WG_THREADS
 #undef WG_WAVES

@@ -480,6 +480,7 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
     for (const EngProb& P : sorted) if (P.mirror) grid = false;
   }
   pl.ext = grid;
+  hipEvent_t e0_at_kernel = nullptr;
   auto run = [&](EngProb* ps, int np) -> int {
     EngCfg cfg; size_t lds_bytes;
     plan_cfg(pl, c->L, trunc, cfg, lds_bytes);
@@ -506,6 +507,7 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
     EngProb* d_probs = (EngProb*)(c->scratch.base + (((size_t)nslots * slot_bytes + 255) & ~size_t(255)));
     HIPCHK(c, hipMemcpyAsync(d_probs, ps, sizeof(EngProb) * np, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream));
+    if (e0_at_kernel) hipEventRecord(e0_at_kernel, c->stream);      // the workgroup form is timed kernel only (host planning excluded)
     if (pl.small) hipLaunchKernelGGL(v64::eng_kernel, dim3(nslots), dim3(64), lds_bytes, c->stream, d_probs, np, c->d_counter, cfg, d_scr, c->d_stats);
     else hipLaunchKernelGGL(v512::eng_kernel, dim3(nslots), dim3(512), lds_bytes, c->stream, d_probs, np, c->d_counter, cfg, d_scr, c->d_stats);
     (void)kern;
@@ -515,7 +517,8 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   const bool timed = count_as_orth && c->profiling;
   EventPair lev;
   hipEvent_t e0 = timed ? lev.a : nullptr, e1 = lev.b;
-  if (timed) hipEventRecord(e0, c->stream);
+  e0_at_kernel = (timed && !grid) ? e0 : nullptr;
+  if (timed && grid) hipEventRecord(e0, c->stream);                 // batched form: gauge sweep + sweep 2 together
   if (!grid) {
     int rc = run(sorted.data(), nprob);
     if (rc != MPBP_OK) return rc;

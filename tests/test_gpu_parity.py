@@ -224,7 +224,7 @@ def _saturate_inputs(bp, g, nodes, Mb, seed):
     bp.set_messages(msgs)
 
 
-def test_full_size_config3_glauber_er_properties():
+def test_full_size_baseline_configs2_glauber_er_properties():
     """BASELINE configs[2] at its stated dimensions (homogeneous Glauber J=0.5, h=0, beta=1 on
     networkx.gnp_random_graph(2048, 4/2047, seed=0), T=100, TruncBond(30); glauber_bp.jl:22-44,128-131): one update, at
     saturated incoming bonds, of nodes of degree 0 .. 6 (product bond 900, nstates = l+1 growing along the cavity:
@@ -250,7 +250,7 @@ def test_full_size_config3_glauber_er_properties():
     assert np.isfinite(M.bethe_free_energy(bp))
 
 
-def test_full_size_config4_karate_properties():
+def test_full_size_baseline_configs3_karate_properties():
     """BASELINE configs[3] at its stated dimensions (SIS lambda=0.1 rho=0.05 on notebooks/karate.txt, node 0 infected at
     t=0, T=200, TruncBond(40)): one update at saturated incoming bonds of nodes of degree 1 .. 5 (products of bond
     40 x 40 = 1600, Y_t = 6400 x 1600).  Full sweeps over the whole graph including the two hubs (cavity chains of 46 /
@@ -271,7 +271,7 @@ def test_full_size_config4_karate_properties():
     assert np.isfinite(M.bethe_free_energy(bp))
 
 
-def test_full_size_config5_infinite_graph_properties():
+def test_full_size_baseline_configs4_infinite_graph_properties():
     """BASELINE configs[4] at its stated dimensions (src/infinite_graph.jl:8-43: k=3 copies of one message, SIS
     lambda=0.1 rho=0.2, gamma=0.1, T=200, TruncBond(64)): four in-place iterations - bonds 2, 8, 64 and then one
     iteration with every product at bond 64 x 64 = 4096 (Y_t = 16384 x 4096, 537 MB per time step)."""

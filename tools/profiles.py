@@ -1,33 +1,35 @@
-"""Assemble profiles/r01_* from the raw rocprofv3 / bench output of one gpurun call (see profiles/README.md)."""
-import csv, json, shutil, sys
+"""Assemble profiles/r02_* from the raw output of one gpurun call of tools/r02_profiles.sh (see profiles/README.md).
+Run from the repository root."""
+import csv, json, shutil
 G = "gpurun_out/"
-shutil.copy(G + "r01_bench.json", "profiles/r01_bench.json")
-shutil.copy(G + "r01_bench_under_rocprof.json", "profiles/r01_bench_under_rocprof.json")
-with open(G + "r01_phase.txt") as f:
-    lines = [l for l in f if "amdgpu.ids" not in l]
-open("profiles/r01_engine_phase_profile.txt", "w").writelines(lines)
+R = "profiles/r02_"
+shutil.copy(G + "r02_bench.json", R + "bench.json")
+shutil.copy(G + "r02_bench_under_rocprof.json", R + "bench_under_rocprof.json")
+with open(G + "r02_phase.txt") as f:
+    lines = [l for l in f if "amdgpu.ids" not in l and not l.startswith("[bench]")]
+open(R + "engine_phase_profile.txt", "w").writelines(lines)
 rows = list(csv.reader(open(G + "profK/p_kernel_stats.csv")))
-csv.writer(open("profiles/r01_bench_kernel_stats.csv", "w")).writerows([[c[:110] for c in r] for r in rows[:12]])
+csv.writer(open(R + "bench_kernel_stats.csv", "w")).writerows([[c[:110] for c in r] for r in rows[:12]])
 tr = list(csv.DictReader(open(G + "profK/p_kernel_trace.csv")))
 eng = [r for r in tr if "eng_kernel" in r["Kernel_Name"]]
-with open("profiles/r01_eng_kernel_dispatches.csv", "w") as f:
+with open(R + "eng_kernel_dispatches.csv", "w") as f:
     f.write("dispatch,variant,grid_x,workgroup_x,duration_ms\n")
     for i, r in enumerate(eng):
         f.write(f"{i},{r['Kernel_Name'][:4].strip(':')},{r['Grid_Size_X']},{r['Workgroup_Size_X']},"
                 f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6:.6f}\n")
-# timed cavity launches under rocprof: the v512 launches of the last two sweeps
 big = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in eng if r["Kernel_Name"].startswith("v512")]
-timed = big[-4:]
-under = json.load(open(G + "r01_bench_under_rocprof.json"))
-print("rocprof avg of timed v512 launches: %.3f ms; bench HIP events: %.3f ms" % (sum(timed) / len(timed), under["roofline"]["avg_launch_ms"]))
+timed = big[-4:]          # the v512 cavity launches of the two timed sweeps
+under = json.loads(open(G + "r02_bench_under_rocprof.json").read().strip().splitlines()[-1])
+print("rocprof avg of the timed v512 launches: %.3f ms; bench HIP events in the same process: %.3f ms" % (sum(timed) / len(timed), under["roofline"]["avg_launch_ms"]))
 out, tot = {}, {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = list(csv.reader(open(G + f"pmc_{c}/p_counter_collection.csv")))
-    keep = [rows[0]] + [r for r in rows[1:] if "eng_kernel" in r[8]]
-    csv.writer(open(f"profiles/r01_pmc_{c}_eng_kernel_dispatches.csv", "w")).writerows(keep)
     h = rows[0]
-    v512 = [r for r in keep[1:] if r[h.index("Kernel_Name")].startswith("v512")]
-    tot[c] = [float(r[h.index("Counter_Value")]) for r in v512[-2:]]
+    kn, cv = h.index("Kernel_Name"), h.index("Counter_Value")
+    keep = [rows[0]] + [r for r in rows[1:] if "eng_kernel" in r[kn]]
+    csv.writer(open(R + f"pmc_{c}_eng_kernel_dispatches.csv", "w")).writerows(keep)
+    v512 = [r for r in keep[1:] if r[kn].startswith("v512")]
+    tot[c] = [float(r[cv]) for r in v512[-2:]]
     out[c + "_KiB_per_launch"] = tot[c]
 fetch = sum(tot["FETCH_SIZE"]) * 1024 * 2      # gfx950: 128-B requests tallied at 64 B (MI355X_MICROARCH.md, HBM section)
 write = sum(tot["WRITE_SIZE"]) * 1024
@@ -35,9 +37,32 @@ out.update({"launches": 2, "bytes_per_launch_avg": (fetch + write) / 2, "fetch_b
             "write_bytes_total": write,
             "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 1 --warmup 3 --no-cpu-baseline",
             "note": "memory-side (L2 fabric) traffic of the two v512::eng_kernel launches of the timed sweep; Infinity-Cache hits are included in these counters"})
-json.dump(out, open("profiles/r01_pmc_eng_kernel.json", "w"), indent=1)
+json.dump(out, open(R + "pmc_eng_kernel.json", "w"), indent=1)
 print("traffic per launch (avg): %.3f TB" % (out["bytes_per_launch_avg"] / 1e12))
-# the bench line of this same call quoted the previous PMC file: make it carry this call's measurement
-b = json.load(open("profiles/r01_bench.json"))
+# MFMA counters of the same launches
+rows = list(csv.DictReader(open(G + "pmc_MFMA/p_counter_collection.csv")))
+v512 = [r for r in rows if r["Kernel_Name"].startswith("v512")]
+disp = sorted(set(int(r["Dispatch_Id"]) for r in v512))[-2:]
+m = {}
+for r in v512:
+    if int(r["Dispatch_Id"]) in disp:
+        m.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+res = {k: v for k, v in m.items()}
+if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m:
+    # SQ_VALU_MFMA_BUSY_CYCLES = matrix-pipe busy cycles summed over the 1024 SIMDs (= 64 per v_mfma_f64_16x16x4: it equals
+    # SQ_INSTS_VALU_MFMA_F64 x 64 to the digit); SQ_BUSY_CYCLES = busy cycles summed over the 32 shader engines
+    res["mfma_pipe_utilisation"] = [a / (b / 32.0 * 1024.0) for a, b in zip(m["SQ_VALU_MFMA_BUSY_CYCLES"], m["SQ_BUSY_CYCLES"])]
+res["command"] = "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 --output-format csv -- python3 bench.py --steps 1 --warmup 3 --no-cpu-baseline"
+res["note"] = ("the two v512::eng_kernel launches of the timed sweep; counter semantics as rocprofv3 reports them on gfx950 "
+               "(summed over shader engines / XCDs); SQ_INSTS_VALU_MFMA_F64 x 2048 flop = executed MFMA flops")
+if "SQ_INSTS_VALU_MFMA_F64" in m:
+    res["mfma_flops_per_launch"] = [v * 2048 for v in m["SQ_INSTS_VALU_MFMA_F64"]]
+json.dump(res, open(R + "pmc_mfma.json", "w"), indent=1)
+print({k: v for k, v in res.items() if k not in ("command", "note")})
+b = json.loads(open(R + "bench.json").read().strip().splitlines()[-1])
 b["roofline"]["traffic"] = out["bytes_per_launch_avg"]
-json.dump(b, open("profiles/r01_bench.json", "w"), indent=1)
+b["roofline"]["traffic_source"] = "profiles/r02_pmc_eng_kernel.json (same command under rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE per launch)"
+if b["roofline"].get("avg_launch_ms"):
+    b["roofline"]["hbm_GBps"] = out["bytes_per_launch_avg"] / (b["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+    b["roofline"]["frac_hbm"] = b["roofline"]["hbm_GBps"] / 8000.0
+json.dump(b, open(R + "bench.json", "w"), indent=1)
