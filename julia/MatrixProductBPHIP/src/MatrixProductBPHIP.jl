@@ -182,6 +182,7 @@ function MatrixProductBP.iterate!(bp::MPBP, be::HIPBackend; maxiter::Integer=5, 
             foreach(i -> sweep([i]), nodes)
         end
         be.stats.nan_flag != 0 && @error "NaN in tensor train"
+        be.stats.jacobi_not_converged != 0 && @warn "a Jacobi SVD hit its sweep limit in this update"
         be.stats.capacity_flag != 0 && @warn "a bond hit max_bond: results differ from the reference"
         svd_trunc isa TruncBondMax && (svd_trunc.maxerr[] = max(svd_trunc.maxerr[], be.stats.maxerr))
         pull_beliefs!(bp, be)
@@ -194,5 +195,30 @@ function MatrixProductBP.iterate!(bp::MPBP, be::HIPBackend; maxiter::Integer=5, 
     pull_messages && pull_messages!(bp, be)
     return maxiter, cb
 end
+
+"""
+    twovar_marginals_device(bp, be; sites, maxdist) -> Array{Float64,5}  # [x_t, x_u, u, t, k]
+
+Two-time marginals of the beliefs of `sites` computed on the device (`mpbp_twovar_marginals`; replaces the
+`twovar_marginals(bp.b[i]; maxdist)` scan behind `autocorrelations` / `autocovariances`, src/mpbp.jl:245-255).
+Entries with `u <= t` or `u > t + maxdist` are zero.
+"""
+function twovar_marginals_device(bp::MPBP, be::HIPBackend; sites=collect(vertices(bp.g)), maxdist::Integer=getT(bp) + 1)
+    L = getT(bp) + 1; q = be.q
+    out = zeros(Float64, q, q, L, L, length(sites))
+    check(ccall((:mpbp_twovar_marginals, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Float64}),
+                be.h, Int32.(sites .- 1), length(sites), maxdist, out), be.h)
+    out
+end
+
+"""
+    allgather_slots!(be, comm, rank, world, slots_per_rank)
+
+Exchange step of the multi-GPU path: one in-place RCCL all-gather of the message slab and one of the bond table
+(`mpbp_allgather_slots`; `comm` is the `ncclComm_t` of the host's RCCL binding).  Makes the messages written by every
+rank's `mpbp_sweep` visible on all ranks - the `bp.μ[idx(e)] = μj` of src/recursive_bp_factor.jl:177 across GPUs.
+"""
+allgather_slots!(be::HIPBackend, comm::Ptr{Cvoid}, rank::Integer, world::Integer, S::Integer) =
+    check(ccall((:mpbp_allgather_slots, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Int32), be.h, comm, rank, world, S), be.h)
 
 end # module

@@ -370,7 +370,7 @@ struct EngLaunchPlan {
 // one wave (rows of Y_t = B*ny*q <= QR_RS*64): these are the latency-bound problems (finalisation, products with
 // the bond-1 initial train, low bond dimensions).  MPBP_DEBUG_NO_SMALL=1 sends everything to the 512-thread one.
 static inline bool small_problem(int64_t B, int ny, int q) {
-  static const bool off = [] { const char* e = getenv("MPBP_DEBUG_NO_SMALL"); return e && e[0] == '1'; }();
+  const bool off = [] { const char* e = getenv("MPBP_DEBUG_NO_SMALL"); return e && e[0] == '1'; }();
   return !off && B * ny * q <= v64::wg::QR_RS * 64;
 }
 
@@ -461,7 +461,7 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
     }
     pl.cap1 = std::min(pl.cap1, a1); pl.cap2 = std::min(pl.cap2, a2);
   }
-  static const bool no_small = [] { const char* e = getenv("MPBP_DEBUG_NO_SMALL"); return e && e[0] == '1'; }();
+  const bool no_small = [] { const char* e = getenv("MPBP_DEBUG_NO_SMALL"); return e && e[0] == '1'; }();
   if (!pl.small && !no_small && (int64_t)pl.cap1 * pl.cap2 * pl.ny * pl.q <= v64::wg::QR_RS * 64 && nprob > 2 * c->num_cu) pl.small = true;
   // few single-wave problems (at most two rounds of 512-thread workgroups): the 512-thread engine finishes them
   // sooner, a single wave per problem only pays off when there are enough problems to fill 4 of them per CU

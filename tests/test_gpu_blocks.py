@@ -130,3 +130,17 @@ def test_qr_batched_tall(rows, cols):
         sgn = np.sign(np.diag(Rn)) * np.sign(np.diag(R[p]))
         sgn[sgn == 0] = 1
         assert np.abs(R[p] * sgn[:, None] - Rn).max() < 1e-11 * np.abs(Rn).max()
+
+
+def test_qr_batched_many_problems_fused_update():
+    """Enough problems for the wave-per-tile-pair fused trailing update (k_trail4f) and the one-launch register panels
+    with Gram + T (k_fpanel), the path a configs[1]-sized batch takes in the batched gauge sweep."""
+    rng = np.random.default_rng(23)
+    for (r, c) in [(200, 150), (352, 208)]:
+        A = rng.standard_normal((600, r, c)) * np.logspace(0, -8, c)[None, None, :]
+        R, _ = _qr_batched(A, 0)
+        for p in (0, 17, 599):
+            Rn = np.linalg.qr(A[p], mode="r")
+            sgn = np.sign(np.diag(Rn)) * np.sign(np.diag(R[p]))
+            sgn[sgn == 0] = 1
+            assert np.abs(R[p] * sgn[:, None] - Rn).max() < 1e-11 * np.abs(Rn).max(), (r, c, p)

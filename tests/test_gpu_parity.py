@@ -104,6 +104,28 @@ def test_sis_loopy_jacobi_sweeps_match_oracle(N, T, Mb, sweeps):
     assert np.array_equal(bp.bonds(), ob)
 
 
+@pytest.mark.parametrize("mode", ["grid", "grid_colstep"])
+def test_batched_gauge_sweep_matches_oracle(mode, monkeypatch):
+    """The same loopy parity case with sweep 1 of every cavity product forced through the batched, grid-level gauge sweep
+    (MPBP_GAUGE=grid; register panels, or column-step panels with MPBP_DEBUG_FORCE_TALL=1) instead of the workgroup
+    engine: beliefs, free energy and bonds after every sweep against the oracle."""
+    monkeypatch.setenv("MPBP_GAUGE", "grid")
+    monkeypatch.setenv("MPBP_DEBUG_NO_SMALL", "1")
+    if mode == "grid_colstep":
+        monkeypatch.setenv("MPBP_DEBUG_FORCE_TALL", "1")
+    N, T, Mb = 8, 6, 6
+    lam, rho, gam = 0.15, 0.1, 0.2
+    A, phi = _loopy(N, T, lam, rho, gam)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    for s in range(3):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+    assert abs(M.bethe_free_energy(bp) - O.bethe_free_energy(obp)) < RTOL * max(1.0, np.abs(obp.f).sum())
+    assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
+
+
 def test_glauber_small_tree_gpu():
     """reference test/glauber_small_tree.jl:3-72 structure (star of 4 + isolated node, T=2,
     TruncBondThresh(10)); HomogeneousGlauberFactor with growing nstates = l+1."""

@@ -1,7 +1,7 @@
 """Convergence run of BASELINE configs[1] (SIS, 3-regular N=1024, T=50, bond 20): 25 Jacobi sweeps through `iterate`
 with the reference callback; prints the belief changes per sweep.  usage: python tools/converge.py"""
 import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import networkx as nx
 import mpbp_amd as M
 N, T, Mb = 1024, 50, 20

@@ -1,6 +1,6 @@
 """Jacobi SVD building block, LDS resident: 512-thread and single-wave variants."""
 import ctypes as C, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import mpbp_amd
 L = mpbp_amd._lib.lib()
 L.mpbp_selftest_jacobi_bench.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_double)] * 2

@@ -1,5 +1,6 @@
+"""Phase split of the workgroup-form QR micro-benchmark (run with MPBP_QR_PROF=1)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mpbp_amd
 L = mpbp_amd._lib.lib()
 ms = C.c_double(0)

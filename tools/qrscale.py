@@ -1,6 +1,6 @@
 """QR building block at different numbers of concurrent workgroups (contention vs latency floor)."""
 import ctypes as C, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import mpbp_amd
 L = mpbp_amd._lib.lib()
 ms = C.c_double()
