@@ -80,6 +80,12 @@ typedef struct {
   void* ext_cores;   /* double[n_slots * core_slot_doubles] */
   void* ext_bonds;   /* int32 [n_slots * (T+2)] */
   void* stream;      /* hipStream_t to launch on; NULL => the context creates its own */
+  /* 1: chains periodic in time (`periodic_mpbp`, reference src/mpbp.jl:399-409): the factor of the last time couples
+   * x^{T+1} back to x^1 (`w[i][end](x^1, x_nbrs^{T+1}, x^{T+1})`, src/exact.jl:24-26; `_f_bp_partial` for periodic trains,
+   * src/recursive_bp_factor.jl:89-101).  Messages stay OPEN trains on the device (bond-1 ends): the value of x_i^1 is
+   * carried through the chain as one more factor q of the bond of the MPEM3 -> MPEM2 embedding and closed on the last
+   * site - the same functions the reference represents as trace-closed PeriodicMPEM2.  Needs q*q*max_bond <= 256. */
+  int32_t periodic;
 } mpbp_desc;
 
 typedef struct {

@@ -29,6 +29,7 @@ struct Desc                        # mpbp_desc, same field order as the header
     max_bond::Int32; device::Int32
     slot_of_edge::Ptr{Int32}; n_slots::Int32
     ext_cores::Ptr{Cvoid}; ext_bonds::Ptr{Cvoid}; stream::Ptr{Cvoid}
+    periodic::Int32                # 1 for `periodic_mpbp` (MPBP{...,<:PeriodicMPEM2,...}, src/mpbp.jl:113-114)
 end
 
 mutable struct Stats               # mpbp_stats
@@ -78,7 +79,7 @@ function HIPBackend(bp::MPBP; max_bond::Integer, device::Integer=0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve nbr_ptr in_edge out_edge begin
         d = Desc(N, E, T, q, pointer(nbr_ptr), pointer(in_edge), pointer(out_edge), max_bond, device,
-                 C_NULL, 0, C_NULL, C_NULL, C_NULL)
+                 C_NULL, 0, C_NULL, C_NULL, C_NULL, Int32(MatrixProductBP.is_periodic(bp)))
         check(ccall((:mpbp_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{Desc}), h, d))
     end
     be = HIPBackend(h[], N, E, T, q, Stats())

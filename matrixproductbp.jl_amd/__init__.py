@@ -6,7 +6,7 @@ from ._lib import MPBPError, build
 from .factors import (DampedFactor, HomogeneousGlauberFactor, IntegerGlauberFactor, PMJGlauberFactor,
                       RecursiveBPFactor, SIRSFactor, SIS_heterogeneousFactor, SISFactor, glauber_factors)
 from .models import SIS, Glauber, Ising
-from .mpbp import (CB_BP, MPBP, random_message, autocorrelations, autocovariances, belief_train, beliefs_tu, twovar_marginals, IndexedBiDiGraph, InfiniteBipartiteRegularGraph, InfiniteRegularGraph, TruncBond,
+from .mpbp import (CB_BP, MPBP, random_message, periodic_mpbp, periodic_mpbp_infinite_graph, is_periodic, autocorrelations, autocovariances, belief_train, beliefs_tu, twovar_marginals, IndexedBiDiGraph, InfiniteBipartiteRegularGraph, InfiniteRegularGraph, TruncBond,
                    TruncBondMax, TruncBondThresh, TruncThresh, beliefs, bethe_free_energy, color_classes,
                    default_truncator, iterate, means, mpbp, mpbp_infinite_bipartite_graph, mpbp_infinite_graph,
                    onebpiter, pair_beliefs, reset_messages, pair_beliefs_as_mpem, pair_correlations,

@@ -31,7 +31,7 @@ class Desc(C.Structure):
                 ("nbr_ptr", C.POINTER(C.c_int32)), ("in_edge", C.POINTER(C.c_int32)),
                 ("out_edge", C.POINTER(C.c_int32)), ("max_bond", C.c_int32), ("device", C.c_int32),
                 ("slot_of_edge", C.POINTER(C.c_int32)), ("n_slots", C.c_int32),
-                ("ext_cores", C.c_void_p), ("ext_bonds", C.c_void_p), ("stream", C.c_void_p)]
+                ("ext_cores", C.c_void_p), ("ext_bonds", C.c_void_p), ("stream", C.c_void_p), ("periodic", C.c_int32)]
 
 
 class Layout(C.Structure):

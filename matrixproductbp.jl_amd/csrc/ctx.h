@@ -52,6 +52,8 @@ struct Arena {
 
 struct mpbp_ctx {
   int N = 0, E = 0, T = 0, L = 0, q = 0, cap = 0, device = 0, nslots = 0;
+  bool periodic = false;          // time-periodic chains (mpbp_desc::periodic)
+  int ct_factor() const { return periodic ? q * q : q; }   // bond factor of the MPEM3 -> MPEM2 embedding
   std::vector<int> nbr_ptr, in_edge, out_edge, slot_of_edge;
   std::vector<NodeFactor> fac;
   std::vector<double> phi, psi;           // host copies (ABI layouts)

@@ -129,6 +129,9 @@ struct CtProb {
   const double* W;      // W[t*(q*q*qj*ny) + x' + q*(xi + q*(xj + qj*y))]
   int32_t q, qj;
   double* out; int32_t* obond; int64_t ostride; double* ologz;
+  int32_t periodic;     // chains periodic in time: one more bond factor q carries c = x_i^1 to the last site, whose factor
+                        // depends on x' = x^{T+2} = x^1:  Ct[t][(m,a,c),(n,x',c'),(xi,xj)] = delta(a,xi) delta(c,c') B[t][...],
+                        // first core: delta(c',xi) B, last core: delta(a,xi) B[..., x' = c]
 };
 
 __global__ void ctilde_kernel(const CtProb* probs, int L) {
@@ -136,7 +139,8 @@ __global__ void ctilde_kernel(const CtProb* probs, int L) {
   const int t = blockIdx.x;
   const int q = P.q, qj = P.qj, ny = P.ny;
   const int bl = P.ibond[t], br = P.ibond[t + 1];
-  const int cl = (t == 0) ? 1 : bl * q, cr = (t == L - 1) ? 1 : br * q;
+  const int mem = P.periodic ? q : 1;             // size of the carried x_i^1 index
+  const int cl = (t == 0) ? 1 : bl * q * mem, cr = (t == L - 1) ? 1 : br * q * mem;
   if (threadIdx.x == 0) {
     P.obond[t] = cl;
     if (t == L - 1) { P.obond[L] = 1; *P.ologz = P.ilogz ? *P.ilogz : 0.0; }
@@ -144,18 +148,23 @@ __global__ void ctilde_kernel(const CtProb* probs, int L) {
   const double* A = P.in + (int64_t)t * P.istride;
   const double* W = P.W + (int64_t)t * q * q * qj * ny;
   double* O = P.out + (int64_t)t * P.ostride;
-  const int na = (t == 0) ? 1 : q, nxp = (t == L - 1) ? 1 : q;
+  const bool first = t == 0, last = t == L - 1;
   const int tot = cl * cr * q * qj;
   for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
     int row = idx % cl; int rest = idx / cl; int col = rest % cr; rest /= cr; int xi = rest % q; int xj = rest / q;
-    int m = row % bl, aa = row / bl;            // (m,a): m fastest (t==0: bl==1 -> m=0, aa=0)
-    int n = col % br, xp = col / br;            // (n,x')
+    const int m = row % bl; const int ra = row / bl; const int aa = ra % q, cc = ra / q;     // (m, a, c): m fastest
+    const int n = col % br; const int rx = col / br; int xp = rx % q; const int cp = rx / q;   // (n, x', c')
+    bool keep = first || aa == xi;
+    if (P.periodic) {
+      if (first) keep = cp == xi;                 // the memory index is created from x_i^1
+      else if (!last) keep = keep && cc == cp;    // and carried unchanged
+      if (last) xp = cc;                          // closed on the last site: x' = x_i^1
+    }
     double v = 0.0;
-    if (na == 1 || aa == xi) {
+    if (keep) {
       for (int y = 0; y < ny; y++)
         v += W[xp + q * (xi + q * (xj + qj * y))] * A[m + bl * (n + br * (y + ny * xi))];
     }
-    (void)nxp;
     O[idx] = v;
   }
 }

@@ -19,7 +19,7 @@ extern "C" int mpbp_create(mpbp_ctx** out, const mpbp_desc* d) {
   if (d->n_nodes <= 0 || d->n_edges <= 0 || d->T < 1 || d->q < 1 || d->q > 4 || d->max_bond < 1 || !d->nbr_ptr ||
       !d->in_edge || !d->out_edge) { g_create_error = "invalid descriptor (need n_nodes,n_edges>0, T>=1, 1<=q<=4, max_bond>=1)"; return MPBP_EINVAL; }
   mpbp_ctx* c = new mpbp_ctx();
-  c->N = d->n_nodes; c->E = d->n_edges; c->T = d->T; c->L = d->T + 1; c->q = d->q; c->cap = d->max_bond; c->device = d->device;
+  c->N = d->n_nodes; c->E = d->n_edges; c->T = d->T; c->L = d->T + 1; c->q = d->q; c->cap = d->max_bond; c->device = d->device; c->periodic = d->periodic != 0;
   c->nbr_ptr.assign(d->nbr_ptr, d->nbr_ptr + c->N + 1);
   const int nnz = c->nbr_ptr[c->N];
   c->in_edge.assign(d->in_edge, d->in_edge + nnz);
@@ -74,7 +74,7 @@ extern "C" int mpbp_create(mpbp_ctx** out, const mpbp_desc* d) {
   {
     // belief trains `bp.b[i]` are kept on the device when they fit comfortably (needed by twovar_marginals /
     // autocorrelations, reference src/mpbp.jl:245-255); otherwise mpbp_get_belief_train reports EUNSUPPORTED
-    const int64_t capb = (int64_t)c->q * c->cap;
+    const int64_t capb = (int64_t)c->ct_factor() * c->cap;
     c->bt_stride = capb * capb * c->q;
     c->bt_slot = c->bt_stride * c->L;
     size_t freeb = 0, totb = 0;
@@ -310,8 +310,8 @@ static int build_tables(mpbp_ctx* c) {
             for (int x = 0; x < q; x++)
               for (int xn = 0; xn < q; xn++) {
                 double val;
-                if (t == L - 1) val = PHI(i, t, x);
-                else {
+                if (t == L - 1 && !c->periodic) val = PHI(i, t, x);
+                else {     // (periodic chains: the last factor couples x^{T+1} to x' = x^1, recursive_bp_factor.jl:94-98)
                   double s = 0.0;
                   for (int y = 0; y < nyz; y++)
                     for (int y2 = 0; y2 < ny1; y2++) {
@@ -331,7 +331,7 @@ static int build_tables(mpbp_ctx* c) {
         for (int y = 0; y < nyz; y++)
           for (int x = 0; x < q; x++)
             for (int xn = 0; xn < q; xn++)
-              w[(size_t)t * q * q * nyz + xn + q * (x + (size_t)q * y)] = (t == L - 1) ? PHI(i, t, x) : PY(t, xn, x, y) * PHI(i, t, x);
+              w[(size_t)t * q * q * nyz + xn + q * (x + (size_t)q * y)] = (t == L - 1 && !c->periodic) ? PHI(i, t, x) : PY(t, xn, x, y) * PHI(i, t, x);
       c->wbel_off[i] = ts.add(w);
     }
   }
@@ -601,7 +601,7 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
   // finalisation trains: ctilde (bond 2*cap... = q*cap), engine output (message), belief ctilde
   struct FinRec { int k, j, p, src, ct, out; int nrm = -1, sum = -1, out2 = -1, occ = 0; };
   std::vector<FinRec> fins; std::vector<FinRec> bels;
-  const int capct = q * cap;
+  const int capct = c->ct_factor() * cap;
   for (int k = 0; k < n_nodes; k++) {
     NodePlan& P = plans[k];
     const int i = P.node; const int z = c->fac[i].deg;
@@ -771,7 +771,7 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
       const DevTrain &s = tr[fr.src], &ct = tr[fr.ct];
       CtProb P{};
       P.in = s.cores; P.ibond = s.bonds; P.istride = s.stride; P.ilogz = s.logz; P.ny = s.ny;
-      P.W = c->d_tab + c->wmsg_off[fr.p]; P.q = q; P.qj = q;
+      P.W = c->d_tab + c->wmsg_off[fr.p]; P.q = q; P.qj = q; P.periodic = c->periodic ? 1 : 0;
       P.out = ct.cores; P.obond = ct.bonds; P.ostride = ct.stride; P.ologz = ct.logz;
       (void)f;
       cps.push_back(P);
@@ -781,7 +781,7 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
       const DevTrain &s = tr[fr.src], &ct = tr[fr.ct];
       CtProb P{};
       P.in = s.cores; P.ibond = s.bonds; P.istride = s.stride; P.ilogz = s.logz; P.ny = s.ny;
-      P.W = c->d_tab + c->wbel_off[i]; P.q = q; P.qj = 1;
+      P.W = c->d_tab + c->wbel_off[i]; P.q = q; P.qj = 1; P.periodic = c->periodic ? 1 : 0;
       P.out = ct.cores; P.obond = ct.bonds; P.ostride = ct.stride; P.ologz = ct.logz;
       cps.push_back(P);
     }
@@ -840,7 +840,7 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
       rv_off.push_back(rv_doubles); rv_doubles += (size_t)(L + 1) * capct;
       eps.push_back(P);
     }
-    if (capct > 256) return c->fail(MPBP_EUNSUPPORTED, "q*max_bond > 256 not supported by the scan kernels yet");
+    if (capct > 256) return c->fail(MPBP_EUNSUPPORTED, "q*max_bond (q*q*max_bond for periodic chains) > 256 not supported by the scan kernels yet");
     auto run_env = [&](std::vector<EnvProb>& ev, const std::vector<size_t>& off, size_t rvd) -> int {
       if (ev.empty()) return MPBP_OK;
       int rc2 = ensure_arena(c, c->scratch, sizeof(EnvProb) * ev.size() + sizeof(double) * rvd + 8192);
@@ -993,7 +993,7 @@ extern "C" int mpbp_twovar_marginals(mpbp_ctx* c, const int32_t* nodes, int32_t 
   hipSetDevice(c->device);
   const int L = c->L, q = c->q;
   if (maxdist < 1 || maxdist > L) maxdist = L;
-  const int bmax = q * c->cap;
+  const int bmax = c->ct_factor() * c->cap;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<int32_t> b0(c->N);
   HIPCHK(c, hipMemcpy2D(b0.data(), sizeof(int32_t), c->d_bbond, sizeof(int32_t) * (L + 1), sizeof(int32_t), c->N, hipMemcpyDeviceToHost));

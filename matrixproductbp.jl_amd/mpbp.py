@@ -205,7 +205,7 @@ class MPBP:
     `ψ[e][t][x_i,x_j]`; messages `μ`, beliefs `b` and free-energy terms `f` live on the device."""
 
     def __init__(self, g, w, phi, psi, q, T, max_bond=None, device=0, slot_of_edge=None, n_slots=0,
-                 ext_cores=None, ext_bonds=None, stream=None):
+                 ext_cores=None, ext_bonds=None, stream=None, periodic=False):
         N, E = g.nv(), g.ne()
         assert len(w) == len(phi) == N, f"{len(w)}, {len(phi)}, {N}"          # src/mpbp.jl:20
         assert len(psi) == E
@@ -245,6 +245,8 @@ class MPBP:
         d.ext_cores = ext_cores
         d.ext_bonds = ext_bonds
         d.stream = stream
+        d.periodic = 1 if periodic else 0
+        self.periodic = bool(periodic)
         h = C.c_void_p()
         _lib.check(L.mpbp_create(C.byref(h), C.byref(d)))
         self._h = h
@@ -369,6 +371,22 @@ def mpbp(g, w, q, T, d=1, phi=None, psi=None, max_bond=None, **kw):
     phi = [[np.ones(q[i]) for _ in range(T + 1)] for i in range(N)] if phi is None else phi
     psi = [[np.ones((q[i], q[j])) for _ in range(T + 1)] for (i, j, _) in g.edges()] if psi is None else psi
     return MPBP(g, w, phi, psi, q, T, max_bond=max_bond, **kw)
+
+
+def periodic_mpbp(g, w, q, T, phi=None, psi=None, max_bond=None, **kw):
+    """`periodic_mpbp` (src/mpbp.jl:399-409): chains periodic in time - `w[i][T+1]` couples x^{T+1} back to x^1
+    (src/exact.jl:24-26).  On the device the messages stay open trains (mpbp_desc::periodic, include/mpbp_hip.h)."""
+    return mpbp(g, w, q, T, phi=phi, psi=psi, max_bond=max_bond, periodic=True, **kw)
+
+
+def periodic_mpbp_infinite_graph(k, wi, qi, phi_i=None, psi=None, max_bond=None, **kw):
+    """`periodic_mpbp_infinite_graph` (src/infinite_graph.jl:37-43)"""
+    return mpbp_infinite_graph(k, wi, qi, phi_i, psi, max_bond=max_bond, periodic=True, **kw)
+
+
+def is_periodic(bp):
+    """src/mpbp.jl:113-114"""
+    return bool(bp.periodic)
 
 
 def mpbp_infinite_graph(k, wi, qi, phi_i=None, psi=None, max_bond=None, **kw):

@@ -147,6 +147,90 @@ def test_glauber_small_tree_gpu():
     assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
 
 
+def _exact_logZ_periodic(obp):
+    with np.errstate(divide="ignore"):
+        return exact_prob(obp, periodic=True)
+
+
+def test_periodic_glauber_small_tree_exact_gpu():
+    """reference test/periodic.jl:1-68: chains periodic in time (`periodic_mpbp`, src/mpbp.jl:399-409; periodic
+    `_f_bp_partial`, src/recursive_bp_factor.jl:89-101) on the 5-node tree with pair observations, node observations and a
+    biased phi at every first time; beliefs, Z, pair beliefs and autocorrelations against brute-force enumeration
+    (src/exact.jl:24-26) with non-binding truncation."""
+    from oracle.exact import exact_autocorrelations
+    T = 2
+    J = np.array([[0, 1, 0, 0, 0], [1, 0, 1, 1, 0], [0, 1, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 0, 0, 0]], float)
+    N = 5
+    rng = np.random.default_rng(111)
+    h = rng.standard_normal(N)
+    g = M.IndexedBiDiGraph(J != 0)
+    psi = [[np.ones((2, 2)) for _ in range(T + 1)] for _ in range(g.E)]
+    obs = [(0, 1, 0, np.array([[0.1, 0.9], [0.3, 0.4]])), (1, 3, 1, np.array([[0.4, 0.6], [0.5, 0.9]])),
+           (1, 2, T, rng.random((2, 2)) + 0.05)]
+    for (i, j, t, m) in obs:
+        for (a, b, e) in g.edges():
+            if (a, b) == (i, j):
+                psi[e][t] = m
+            if (a, b) == (j, i):
+                psi[e][t] = m.T.copy()
+    phi = [[np.array([0.75, 0.25]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    phi[2][1] = np.array([0.0, 1.0])                       # hard node observations, as draw_node_observations! leaves them
+    phi[4][2] = np.array([1.0, 0.0])
+    w = M.glauber_factors(J != 0, J, h, 1.0, T)
+    bp = M.periodic_mpbp(g, w, 2, T, phi=phi, psi=psi, max_bond=16)
+    assert M.is_periodic(bp)
+    M.iterate(bp, maxiter=20, svd_trunc=M.TruncBondThresh(16), schedule="colored")
+    ow = OF.glauber_factors(J != 0, J, h, 1.0, T)
+    obp = O.mpbp(O.IndexedBiDiGraph(J != 0), ow, [2] * N, T, phi=phi, psi=psi)
+    p, Z = _exact_logZ_periodic(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+    pb, _ = M.pair_beliefs(bp)
+    assert _rel(_flat(pb), _flat(exact_pair_marginals(obp, p))) < 1e-9
+    f = lambda x, i: 2 * x - 3
+    r = M.autocorrelations(f, bp)
+    rex = exact_autocorrelations(f, obp, p)
+    assert max(np.abs(a - b).max() for a, b in zip(r, rex)) < 1e-9
+    # the open-chain model on the same inputs is a different distribution: the switch is not a no-op
+    bp0 = M.mpbp(g, w, 2, T, phi=phi, psi=psi, max_bond=16)
+    M.iterate(bp0, maxiter=20, svd_trunc=M.TruncBondThresh(16), schedule="colored")
+    assert _rel(_flat(M.beliefs(bp0)), _flat(M.beliefs(bp))) > 1e-4
+
+
+def test_periodic_sis_chain_exact_gpu():
+    """Periodic chains with a longer ring in time (T = 4) and the SIS factor on a 3-node path: enumeration."""
+    T = 4
+    A = np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]])
+    phi = [[np.array([0.6, 0.4]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(3)]
+    phi[0][3] = np.array([0.2, 0.8])
+    bp = M.periodic_mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(0.4, 0.3, 0.05)] * (T + 1)] * 3, 2, T, phi=phi, max_bond=48)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBond(48), schedule="colored")
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(0.4, 0.3, 0.05)] * (T + 1)] * 3, [2] * 3, T, phi=phi)
+    p, Z = _exact_logZ_periodic(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-8
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-8
+
+
+def test_periodic_infinite_graph_matches_complete_graph_gpu():
+    """reference test/periodic.jl:70-110: `periodic_mpbp_infinite_graph` (k = 3 aliases of one message, damping 0.2,
+    TruncBond(10)) against `periodic_mpbp` on the complete graph of k + 1 nodes - the same local fixed point."""
+    T, k, m0 = 2, 3, 0.5
+    wi = [M.HomogeneousGlauberFactor(1.0, 0.0, 1.0)] * (T + 1)
+    phi_i = [np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)]
+    phi_i[1] = np.array([0.4, 0.6])
+    phi_i[T] = np.array([0.95, 0.05])
+    bp = M.periodic_mpbp_infinite_graph(k, wi, 2, phi_i, max_bond=10)
+    M.iterate(bp, maxiter=150, svd_trunc=M.TruncBond(10), tol=1e-12, damp=0.2)
+    N = k + 1
+    A = np.ones((N, N)) - np.eye(N)
+    bpc = M.periodic_mpbp(M.IndexedBiDiGraph(A), [wi] * N, 2, T, phi=[phi_i] * N, max_bond=10)
+    M.iterate(bpc, maxiter=150, svd_trunc=M.TruncBond(10), tol=1e-12, damp=0.2)
+    b_inf, b_c = np.array(M.beliefs(bp)[0]), np.array(M.beliefs(bpc)[0])
+    assert np.abs(b_inf - b_c).max() < 1e-7
+    pb_inf, pb_c = np.array(M.pair_beliefs(bp)[0][0]), np.array(M.pair_beliefs(bpc)[0][0])
+    assert np.abs(pb_inf - pb_c).max() < 1e-7
+
+
 def test_sirs_q3_tree_gpu():
     """reference test/sirs_small_tree.jl (q = 3)."""
     T = 2
