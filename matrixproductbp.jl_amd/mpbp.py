@@ -361,16 +361,24 @@ def random_message(T, q, bond, rng):
 
 
 def mpbp(g, w, q, T, d=1, phi=None, psi=None, max_bond=None, **kw):
-    """src/mpbp.jl:60-70.  Messages start as the normalised uniform bond-1 trains (`d=1` default).
+    """src/mpbp.jl:60-70.  Messages start as `flat_mpem2(q_i, q_j, T; d)` (src/mpbp.jl:66): constant cores of bond
+    `d` (1 at the two ends), normalised - for `d = 1` the library's initial state, for `d > 1` uploaded once.
     `max_bond` is the device capacity of every stored bond (>= the truncation cap used later)."""
-    if d != 1:
-        raise MPBPError(-4, "initial bond size d != 1 is not supported (use set_messages)")
     N = g.nv()
     q = np.atleast_1d(q)
     q = np.full(N, int(q[0])) if q.size == 1 else q
     phi = [[np.ones(q[i]) for _ in range(T + 1)] for i in range(N)] if phi is None else phi
     psi = [[np.ones((q[i], q[j])) for _ in range(T + 1)] for (i, j, _) in g.edges()] if psi is None else psi
-    return MPBP(g, w, phi, psi, q, T, max_bond=max_bond, **kw)
+    bp = MPBP(g, w, phi, psi, q, T, max_bond=max_bond, **kw)
+    if d != 1:
+        if d > bp.max_bond:
+            raise MPBPError(-5, f"initial bond size d = {d} exceeds max_bond = {bp.max_bond}")
+        L, qq = T + 1, bp.q
+        prof = [1] + [d] * T + [1]
+        # constant cores whose product sums to one: every entry of core t equals c_t with prod_t (c_t b_{t+1} q^2) = 1
+        msg = [np.full((prof[t], prof[t + 1], qq, qq), 1.0 / (prof[t + 1] * qq * qq)) for t in range(L)]
+        bp.set_messages([msg] * g.ne())
+    return bp
 
 
 def periodic_mpbp(g, w, q, T, phi=None, psi=None, max_bond=None, **kw):

@@ -231,6 +231,23 @@ def test_periodic_infinite_graph_matches_complete_graph_gpu():
     assert np.abs(pb_inf - pb_c).max() < 1e-7
 
 
+def test_initial_bond_size_d_gpu():
+    """`mpbp(...; d)` with d > 1 (src/mpbp.jl:60-70: `flat_mpem2(q, q, T; d)`): the same uniform function in a redundant
+    bond, so the first sweeps must give what d = 1 gives."""
+    N, T, Mb = 8, 5, 6
+    lam, rho, gam = 0.2, 0.1, 0.15
+    A, phi = _loopy(N, T, lam, rho, gam)
+    g = M.IndexedBiDiGraph(A)
+    bp1 = M.mpbp(g, [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    bp3 = M.mpbp(g, [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, d=3, phi=phi, max_bond=Mb)
+    assert bp3.bonds().max() == 3
+    for _ in range(2):
+        M.iterate(bp1, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+        M.iterate(bp3, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+        assert _rel(_flat(M.beliefs(bp3)), _flat(M.beliefs(bp1))) < 1e-9
+    assert abs(M.bethe_free_energy(bp3) - M.bethe_free_energy(bp1)) < 1e-8
+
+
 def test_sirs_q3_tree_gpu():
     """reference test/sirs_small_tree.jl (q = 3)."""
     T = 2
@@ -479,13 +496,18 @@ def test_infinite_bipartite_graph_matches_oracle():
     assert abs(M.bethe_free_energy(bp) - O.bethe_free_energy(obp)) < RTOL * max(1.0, abs(O.bethe_free_energy(obp)))
 
 
-def test_two_rank_sharded_sweeps_equal_single_rank(tmp_path):
-    """Multi-GPU path end to end: two ranks (sharing the one GPU of this box, gloo rendezvous) each
-    update their node block and all-gather the message slots after every sweep; beliefs and f must equal the
-    single-process run bit for bit up to rounding."""
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_sharded_sweeps_equal_single_rank(tmp_path, backend):
+    """Multi-GPU path end to end: two ranks each update their node block and all-gather the message slots
+    after every sweep; beliefs and f must equal the single-process run up to rounding.  `gloo`: both ranks share the one
+    GPU of the test box (host-staged exchange); `nccl`: the production exchange - RCCL in-place all_gather_into_tensor of
+    the slab, one GPU per rank - needs two GPUs and is skipped otherwise."""
     import os
     import subprocess
     import sys
+    import torch
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL exchange needs one GPU per rank (2 GPUs)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--nodes", "32", "--T", "8", "--bond", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     one = str(tmp_path / "one.npy")
@@ -496,7 +518,7 @@ def test_two_rank_sharded_sweeps_equal_single_rank(tmp_path):
     assert r1.returncode == 0, r1.stderr[-2000:]
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                         "--gpus", "2", "--backend", "gloo"] + common + ["--dump-beliefs", two],
+                         "--gpus", "2", "--backend", backend] + common + ["--dump-beliefs", two],
                         capture_output=True, text=True, env=env, timeout=900)
     assert r2.returncode == 0, r2.stderr[-2000:]
     a = np.load(one, allow_pickle=True).item()

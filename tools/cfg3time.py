@@ -13,8 +13,18 @@ bp = M.Glauber(M.Ising(0.5 * A, np.zeros(N), 1.0), T, phi=phi).mpbp(max_bond=Mb)
 print("setup", time.time() - t0, flush=True)
 deg = A.sum(axis=0).astype(int)
 allnodes = np.arange(N, dtype=np.int32)
-for s in range(2):
-    t0 = time.time(); M.onebpiter(bp, allnodes, M.TruncBond(Mb)); print("full sweep", s, time.time() - t0, "maxbond", bp.bonds().max(), flush=True)
+if os.environ.get("CFG3_RANDOM"):
+    rng = np.random.default_rng(5)
+    ptr, ine, oute = bp.g.nbr_arrays()
+    tgt = [int(i) for i in np.nonzero((deg >= 2) & (deg <= 5))[0][:48]]
+    msgs = [None] * bp.g.ne()
+    for i in tgt:
+        for p_ in range(ptr[i], ptr[i + 1]):
+            msgs[int(ine[p_])] = M.random_message(T, 2, Mb, rng)
+    bp.set_messages(msgs)
+else:
+    for s in range(2):
+        t0 = time.time(); M.onebpiter(bp, allnodes, M.TruncBond(Mb)); print("full sweep", s, time.time() - t0, "maxbond", bp.bonds().max(), flush=True)
 hub = int(np.argmax(deg))
 subs = [] if os.environ.get('CFG3_ONLY_FULL') else [[int(np.nonzero(deg == 4)[0][0])], [int(i) for i in np.nonzero((deg >= 2) & (deg <= 5))[0][:48]]][:(0 if os.environ.get('CFG3_ONLY_FULL') else 2)]
 if len(sys.argv) > 2: subs.append([hub])
