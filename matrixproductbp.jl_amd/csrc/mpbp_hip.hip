@@ -525,10 +525,19 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
   } else {
     for (int done = 0; done < nprob;) {
       int nd = 0;
-      int rc = v2_gauge_sweep(c, sorted.data() + done, nprob - done, hb.data() + (size_t)done * 2 * (c->L + 1), &nd);
+      // The truncating sweep goes to the grid as well when its ranks are plannable (TruncBond / TruncBondMax) and a time
+      // step is heavy enough to pay for its launches (M_t = N_t Lf_{t+1} of >= 0.2 Gflop); else it runs in the
+      // workgroup engine on the factors just computed.  MPBP_SWEEP2=grid|wg forces one.
+      bool s2grid = (trunc.kind == MPBP_TRUNC_BOND || trunc.kind == MPBP_TRUNC_BOND_MAX) &&
+                    2.0 * (double)bmact * (double)bmact * pl.capout * pl.ny * pl.q >= 2e8;
+      if (const char* s2 = getenv("MPBP_SWEEP2")) { if (!strcmp(s2, "grid")) s2grid = trunc.kind == MPBP_TRUNC_BOND || trunc.kind == MPBP_TRUNC_BOND_MAX; else if (!strcmp(s2, "wg")) s2grid = false; }
+      int did2 = 0;
+      int rc = v2_gauge_sweep(c, sorted.data() + done, nprob - done, hb.data() + (size_t)done * 2 * (c->L + 1), s2grid ? &trunc : nullptr, &nd, &did2);
       if (rc != MPBP_OK) return rc;
-      rc = run(sorted.data() + done, nd);
-      if (rc != MPBP_OK) return rc;
+      if (!did2) {
+        rc = run(sorted.data() + done, nd);
+        if (rc != MPBP_OK) return rc;
+      }
       // the triangular factors live in c->v2arena until sweep 2 has consumed them
       HIPCHK(c, hipStreamSynchronize(c->stream));
       done += nd;

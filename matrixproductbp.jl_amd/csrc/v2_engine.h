@@ -8,7 +8,9 @@
 // sets probs[i].lf / lfoff / rdim (pointers into c->v2arena, valid until the next call).  Problems must not be
 // mirrored.  Asynchronous: the caller may enqueue sweep 2 on the same stream right away.
 // `hb`: host copy of the operands' bond tables, [n][2][L+1] (v2_gather_bonds).
-int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n_done);
+// `trunc2` non-null: also run the truncating sweep (sweep 2) in grid-level form - only for rules whose kept rank follows
+// from the dimensions (MPBP_TRUNC_BOND / BOND_MAX); *did_sweep2 tells the caller that the outputs are complete.
+int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const mpbp_trunc* trunc2, int* n_done, int* did_sweep2);
 
 // Bond tables (bond1, bond2; L+1 entries each) of probs[0 .. n) -> host, [n][2][L+1].  Synchronises the stream.
 int v2_gather_bonds(mpbp_ctx* c, const EngProb* probs, int n, std::vector<int32_t>& hb);

@@ -8,6 +8,7 @@ namespace v512 {
 }
 #undef WG_THREADS
 #undef WG_WAVES
+#include "engine_types.h"
 #include "v2_kernels.h"
 #include "ctx.h"
 #include "v2_engine.h"
@@ -167,6 +168,10 @@ struct ProbPlan {
   std::vector<int32_t> rdim;       // [L+1]
   int64_t lf_doubles = 0, y_doubles = 0, z_doubles = 0, e_doubles = 0;
   int rows32_max = 0, cols_max = 0;
+  // truncating sweep (planned when the kept ranks follow from the dimensions)
+  std::vector<int> kc;             // [L+1]: left bond of output core t
+  int64_t c_doubles = 0, t1_doubles = 0, nt_doubles = 0, mt_doubles = 0, ja_doubles = 0, u_doubles = 0;
+  int rr_max = 0;
 };
 
 inline v2::Map2 lin(int64_t s) { return v2::Map2{1 << 30, s, 0}; }
@@ -191,7 +196,8 @@ int v2_gather_bonds(mpbp_ctx* c, const EngProb* probs, int n, std::vector<int32_
   return MPBP_OK;
 }
 
-int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n_done) {
+int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const mpbp_trunc* trunc2, int* n_done, int* did_sweep2) {
+  *did_sweep2 = 0;
   *n_done = 0;
   if (n <= 0) return MPBP_OK;
   const int L = c->L;
@@ -221,7 +227,31 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n
       pp.e_doubles = std::max<int64_t>(pp.e_doubles, (int64_t)P.q * d.b * P.ny * d.bn * P.ny1);
       pp.rows32_max = std::max(pp.rows32_max, r32i(d.rows)); pp.cols_max = std::max(pp.cols_max, d.cols);
     }
+    pp.e_doubles = std::max<int64_t>(pp.e_doubles, (int64_t)P.q * b2[0] * P.ny * b2[1] * P.ny1);
     pp.lf_doubles = off;
+    if (trunc2) {
+      // sweep 2, t = 0 .. L-1: kc_0 = 1, Rr = kc ny q, kept rank min(Rr, r_{t+1}, mprime, cap_out)
+      pp.kc.assign(L + 1, 1);
+      for (int t = 0; t < L; t++) {
+        const int a = b1[t], an = b1[t + 1], b = b2[t], bn = b2[t + 1];
+        const int kc = pp.kc[t], Rr = kc * P.ny * P.q;
+        const int64_t Bn = (int64_t)an * bn;
+        pp.rr_max = std::max(pp.rr_max, Rr);
+        pp.c_doubles = std::max<int64_t>(pp.c_doubles, (int64_t)kc * a * b);
+        pp.t1_doubles = std::max<int64_t>(pp.t1_doubles, (int64_t)kc * b * an * P.ny1 * P.q);
+        pp.nt_doubles = std::max<int64_t>(pp.nt_doubles, (int64_t)Rr * Bn);
+        if (t == L - 1) break;
+        const int r1 = pp.rdim[t + 1];
+        int kp = std::min(std::min(Rr, r1), trunc2->mprime);
+        kp = std::max(1, std::min(kp, (int)P.cap_out));
+        pp.kc[t + 1] = kp;
+        pp.c_doubles = std::max<int64_t>(pp.c_doubles, (int64_t)kp * Bn);
+        pp.mt_doubles = std::max<int64_t>(pp.mt_doubles, (int64_t)r32i(r1) * (r16i(Rr) + 16));
+        pp.ja_doubles = std::max<int64_t>(pp.ja_doubles, (int64_t)(Rr | 1) * std::min(r1, Rr));
+        pp.u_doubles = std::max<int64_t>(pp.u_doubles, (int64_t)Rr * kp);
+        pp.rows32_max = std::max(pp.rows32_max, r32i(r1)); pp.cols_max = std::max(pp.cols_max, Rr);
+      }
+    }
   }
   // ---- how many problems fit
   size_t freeb = 0, totb = 0;
@@ -237,8 +267,9 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n
     size_t tot = 0;
     for (int k = 0; k <= i; k++)
       tot += al(plan[k].y_doubles) + al(plan[k].z_doubles) + al(plan[k].e_doubles) + al(plan[k].lf_doubles) + al(v2::auxlay_doubles(nc, nt)) +
-             (((size_t)(L + 1) * 12 + 255) & ~size_t(255));
-    const size_t desc = (size_t)(i + 1) * L * (sizeof(v2::QrProb) + sizeof(v2::GemmDesc) * (1 + c->q) + sizeof(v2::EDesc) + sizeof(v2::LfDesc)) + 65536;
+             (((size_t)(L + 1) * 12 + 255) & ~size_t(255)) +
+             (trunc2 ? 2 * al(plan[k].c_doubles) + al(plan[k].t1_doubles) + al(plan[k].nt_doubles) + al(plan[k].mt_doubles) + al(plan[k].ja_doubles) + al(plan[k].u_doubles) + 512 : 0);
+    const size_t desc = (size_t)(i + 1) * L * (sizeof(v2::QrProb) * 2 + sizeof(v2::GemmDesc) * (4 + 2 * c->q) + sizeof(v2::EDesc) + sizeof(v2::LfDesc) + sizeof(v2::ScaleDesc) + sizeof(v2::SvdDesc)) + 65536;
     if (i > 0 && tot + desc > budget) break;
     P = i + 1; bytes = tot + desc; nchunk = nc; ntile = nt;
   }
@@ -252,13 +283,19 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n
   // ---- carve the arena
   char* base = c->v2arena.base; size_t used = 0;
   auto take = [&](size_t b) { char* p = base + used; used += (b + 255) & ~size_t(255); return p; };
-  struct Bufs { double *Y, *Z, *E, *aux, *lf; int64_t* lfoff; int32_t* rdim; };
+  struct Bufs { double *Y, *Z, *E, *aux, *lf; int64_t* lfoff; int32_t* rdim; double *C0, *C1, *T1, *Nt, *Mt, *JA, *U, *scal; };
   std::vector<Bufs> bf(P);
   for (int i = 0; i < P; i++) {
     bf[i].Y = (double*)take(al(plan[i].y_doubles)); bf[i].Z = (double*)take(al(plan[i].z_doubles));
     bf[i].E = (double*)take(al(plan[i].e_doubles)); bf[i].aux = (double*)take(al(auxd)); bf[i].lf = (double*)take(al(plan[i].lf_doubles));
     char* tb = take((size_t)(L + 1) * 12);
     bf[i].lfoff = (int64_t*)tb; bf[i].rdim = (int32_t*)(tb + (size_t)(L + 1) * 8);
+    if (trunc2) {
+      bf[i].C0 = (double*)take(al(plan[i].c_doubles)); bf[i].C1 = (double*)take(al(plan[i].c_doubles));
+      bf[i].T1 = (double*)take(al(plan[i].t1_doubles)); bf[i].Nt = (double*)take(al(plan[i].nt_doubles));
+      bf[i].Mt = (double*)take(al(plan[i].mt_doubles)); bf[i].JA = (double*)take(al(plan[i].ja_doubles));
+      bf[i].U = (double*)take(al(plan[i].u_doubles)); bf[i].scal = (double*)take(512);     // [0] max slot, [1] log c
+    }
   }
   // ---- descriptors of all time steps, one upload
   const int q = probs[0].q;
@@ -274,13 +311,17 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n
     memcpy(htab.data() + (size_t)i * (L + 1) * 12, plan[i].lfoff.data(), (size_t)(L + 1) * 8);
     memcpy(htab.data() + (size_t)i * (L + 1) * 12 + (size_t)(L + 1) * 8, plan[i].rdim.data(), (size_t)(L + 1) * 4);
     hone[i].p = bf[i].lf + plan[i].lfoff[L];
+    {
+      const int32_t* b2 = hb + (size_t)i * 2 * (L + 1) + (L + 1);
+      for (int t = 0; t < L; t++)      // the coupling table of every time step (the truncating sweep starts at t = 0)
+        he[(size_t)t * P + i] = v2::EDesc{Pr.A2 + (int64_t)t * Pr.stride2, Pr.pyy + (int64_t)t * Pr.pyy_tstride, bf[i].E, (int)b2[t], (int)b2[t + 1], Pr.ny, Pr.ny1, Pr.ny2, q};
+    }
     for (int t = 1; t < L; t++) {
       const StepDims& d = plan[i].st[t];
       const size_t k = (size_t)t * P + i;
       const int ldY = r32i(d.rows);
       hq[k] = v2::QrProb{bf[i].Y, bf[i].aux, ldY, d.rows, d.cols, d.kmax};
       hl[k].Lf = bf[i].lf + plan[i].lfoff[t];
-      he[k] = v2::EDesc{Pr.A2 + (int64_t)t * Pr.stride2, Pr.pyy + (int64_t)t * Pr.pyy_tstride, bf[i].E, d.b, d.bn, Pr.ny, Pr.ny1, Pr.ny2, q};
       const int64_t zld = (int64_t)d.r1 * d.bn;
       v2::GemmDesc g{};
       g.S = Pr.A1 + (int64_t)t * Pr.stride1; g.X = bf[i].lf + plan[i].lfoff[t + 1]; g.O = bf[i].Z;
@@ -343,5 +384,131 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, int* n
   HIPCHK(c, hipGetLastError());
   for (int i = 0; i < P; i++) { probs[i].lf = bf[i].lf; probs[i].lfoff = bf[i].lfoff; probs[i].rdim = bf[i].rdim; }
   *n_done = P;
+  if (!trunc2) return MPBP_OK;
+  // ================================================================ the truncating sweep on the grid
+  {
+    std::vector<v2::GemmDesc> gn1((size_t)P * L), gn2((size_t)P * L * q), gmt((size_t)P * L), gcr((size_t)P * L);
+    std::vector<v2::QrProb> q2((size_t)P * L);
+    std::vector<v2::ScaleDesc> sc((size_t)P * L);
+    std::vector<v2::SvdDesc> sv((size_t)P * L);
+    std::vector<v2::LastDesc> last(P);
+    std::vector<v2::NormDesc> nrm(P);
+    std::vector<v2::SetOne> one2(P);
+    for (int i = 0; i < P; i++) {
+      const EngProb& Pr = probs[i];
+      const int32_t* b1 = hb + (size_t)i * 2 * (L + 1);
+      const int32_t* b2 = b1 + (L + 1);
+      one2[i].p = bf[i].C0;
+      last[i] = v2::LastDesc{bf[i].Nt, Pr.out + (int64_t)(L - 1) * Pr.ostride, Pr.obond, plan[i].kc[L - 1] * Pr.ny * q, L};
+      nrm[i] = v2::NormDesc{Pr.out, Pr.obond, Pr.ostride, Pr.logz1, Pr.logz2, bf[i].scal + 2, Pr.ologz, Pr.ny * q, L};
+      for (int t = 0; t < L; t++) {
+        const size_t k = (size_t)t * P + i;
+        const int a = b1[t], an = b1[t + 1], b = b2[t], bn = b2[t + 1];
+        const int kc = plan[i].kc[t], Rr = kc * Pr.ny * q;
+        const int64_t Bn = (int64_t)an * bn, tld = (int64_t)kc * b;
+        double* Ccur = (t & 1) ? bf[i].C1 : bf[i].C0;
+        double* Cnew = (t & 1) ? bf[i].C0 : bf[i].C1;
+        v2::GemmDesc g{};
+        g.S = Pr.A1 + (int64_t)t * Pr.stride1; g.X = Ccur; g.O = bf[i].T1;
+        g.M = an * Pr.ny1 * q; g.N = kc * b; g.K = a;
+        g.sro = v2::Map2{an, a, (int64_t)a * an}; g.sco = lin(1);
+        g.xro = lin(kc); g.xco = v2::Map2{kc, 1, (int64_t)kc * a};
+        g.oro = lin(tld); g.oco = lin(1);
+        gn1[k] = g;
+        const int M2 = b * Pr.ny, K2 = bn * Pr.ny1;
+        for (int xi = 0; xi < q; xi++) {
+          v2::GemmDesc h{};
+          h.S = bf[i].E + (int64_t)xi * M2 * K2; h.X = bf[i].T1 + tld * an * Pr.ny1 * xi; h.O = bf[i].Nt + (int64_t)kc * Pr.ny * xi;
+          h.M = bn * Pr.ny; h.N = kc * an; h.K = b * Pr.ny1;
+          h.sro = v2::Map2{bn, M2, b}; h.sco = v2::Map2{b, 1, (int64_t)M2 * bn};
+          h.xro = v2::Map2{b, kc, tld * an}; h.xco = v2::Map2{kc, 1, tld};
+          h.oro = v2::Map2{bn, (int64_t)Rr * an, kc}; h.oco = v2::Map2{kc, 1, Rr};
+          gn2[k * q + xi] = h;
+        }
+        sc[k] = v2::ScaleDesc{bf[i].Nt, (int64_t)Rr * Bn, bf[i].scal + (t & 1), bf[i].scal + 2, bf[i].scal + ((t + 1) & 1)};
+        if (t == L - 1) continue;
+        const int r1 = plan[i].rdim[t + 1], kp = plan[i].kc[t + 1];
+        const int ldM = r32i(r1);
+        v2::GemmDesc m{};
+        m.S = bf[i].Nt; m.X = bf[i].lf + plan[i].lfoff[t + 1]; m.O = bf[i].Mt;
+        m.M = Rr; m.N = r1; m.K = (int)Bn;
+        m.sro = lin(1); m.sco = lin(Rr); m.xro = lin(r1); m.xco = lin(1); m.oro = lin(ldM); m.oco = lin(1);
+        gmt[k] = m;
+        q2[k] = v2::QrProb{bf[i].Mt, bf[i].aux, ldM, r1, Rr, std::min(r1, Rr)};
+        sv[k] = v2::SvdDesc{bf[i].Mt, bf[i].JA, bf[i].U, Pr.out + (int64_t)t * Pr.ostride, Pr.obond,
+                            ldM, r1, Rr, kc, kp, t, L, trunc2->kind, trunc2->mprime, Pr.cap_out};
+        v2::GemmDesc cr{};
+        cr.S = bf[i].U; cr.X = bf[i].Nt; cr.O = Cnew;
+        cr.M = kp; cr.N = (int)Bn; cr.K = Rr;
+        cr.sro = lin(Rr); cr.sco = lin(1); cr.xro = lin(1); cr.xco = lin(Rr); cr.oro = lin(1); cr.oco = lin(kp);
+        gcr[k] = cr;
+      }
+    }
+    v2::GemmDesc* dn1 = (v2::GemmDesc*)take(sizeof(v2::GemmDesc) * gn1.size());
+    v2::GemmDesc* dn2 = (v2::GemmDesc*)take(sizeof(v2::GemmDesc) * gn2.size());
+    v2::GemmDesc* dmt = (v2::GemmDesc*)take(sizeof(v2::GemmDesc) * gmt.size());
+    v2::GemmDesc* dcr = (v2::GemmDesc*)take(sizeof(v2::GemmDesc) * gcr.size());
+    v2::QrProb* dq2 = (v2::QrProb*)take(sizeof(v2::QrProb) * q2.size());
+    v2::ScaleDesc* dsc = (v2::ScaleDesc*)take(sizeof(v2::ScaleDesc) * sc.size());
+    v2::SvdDesc* dsv = (v2::SvdDesc*)take(sizeof(v2::SvdDesc) * sv.size());
+    v2::LastDesc* dlast = (v2::LastDesc*)take(sizeof(v2::LastDesc) * P);
+    v2::NormDesc* dnrm = (v2::NormDesc*)take(sizeof(v2::NormDesc) * P);
+    v2::SetOne* done2 = (v2::SetOne*)take(sizeof(v2::SetOne) * P);
+    if (used > c->v2arena.cap) return c->fail(MPBP_ENOMEM, "internal: gauge-sweep arena accounting (%zu > %zu)", used, c->v2arena.cap);
+    HIPCHK(c, hipMemcpyAsync(dn1, gn1.data(), sizeof(v2::GemmDesc) * gn1.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dn2, gn2.data(), sizeof(v2::GemmDesc) * gn2.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dmt, gmt.data(), sizeof(v2::GemmDesc) * gmt.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dcr, gcr.data(), sizeof(v2::GemmDesc) * gcr.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dq2, q2.data(), sizeof(v2::QrProb) * q2.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dsc, sc.data(), sizeof(v2::ScaleDesc) * sc.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dsv, sv.data(), sizeof(v2::SvdDesc) * sv.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dlast, last.data(), sizeof(v2::LastDesc) * P, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dnrm, nrm.data(), sizeof(v2::NormDesc) * P, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(done2, one2.data(), sizeof(v2::SetOne) * P, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < P; i++) HIPCHK(c, hipMemsetAsync(bf[i].scal, 0, 64, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    hipLaunchKernelGGL(v2::k_set_one, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SetOne*)done2, P);
+    int rrm = 1;
+    for (int i = 0; i < P; i++) rrm = std::max(rrm, plan[i].rr_max);
+    const size_t svd_lds = sizeof(double) * (32 + (size_t)rrm + (rrm + 1) / 2 + 4);
+    HIPCHK(c, hipFuncSetAttribute((const void*)v2::k_svd_trunc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)svd_lds));
+    for (int t = 0; t < L; t++) {
+      int maxN1 = 0, maxN2 = 0, maxNm = 0, maxNc = 0, rows32m = 0; int64_t maxE = 0, maxNt = 0;
+      for (int i = 0; i < P; i++) {
+        const int32_t* b1 = hb + (size_t)i * 2 * (L + 1);
+        const int32_t* b2 = b1 + (L + 1);
+        const int kc = plan[i].kc[t], Rr = kc * probs[i].ny * q;
+        maxN1 = std::max(maxN1, kc * (int)b2[t]); maxN2 = std::max(maxN2, kc * (int)b1[t + 1]);
+        maxE = std::max<int64_t>(maxE, (int64_t)q * b2[t] * probs[i].ny * b2[t + 1] * probs[i].ny1);
+        maxNt = std::max<int64_t>(maxNt, (int64_t)Rr * b1[t + 1] * b2[t + 1]);
+        maxNc = std::max(maxNc, (int)b1[t + 1] * (int)b2[t + 1]);
+        if (t < L - 1) {
+          const int r1 = plan[i].rdim[t + 1];
+          dims[i] = QrDims{r1, Rr, std::min(r1, Rr)};
+          maxNm = std::max(maxNm, r1); rows32m = std::max(rows32m, r32i(r1));
+        }
+      }
+      const size_t o = (size_t)t * P;
+      hipLaunchKernelGGL(v2::k_build_E, dim3((unsigned)std::min<int64_t>(64, (maxE + 255) / 256), P), dim3(256), 0, st, (const v2::EDesc*)(de + o));
+      hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN1 + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dn1 + o));
+      hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN2 + 127) / 128), P * q), dim3(512), 0, st, (const v2::GemmDesc*)(dn2 + o * q));
+      const unsigned gsc = (unsigned)std::min<int64_t>(256, (maxNt + 2047) / 2048);
+      hipLaunchKernelGGL(v2::k_absmax, dim3(gsc, P), dim3(256), 0, st, (const v2::ScaleDesc*)(dsc + o));
+      hipLaunchKernelGGL(v2::k_scale, dim3(gsc, P), dim3(256), 0, st, (const v2::ScaleDesc*)(dsc + o), c->d_stats);
+      if (t == L - 1) {
+        hipLaunchKernelGGL(v2::k_lastcore, dim3(P), dim3(256), 0, st, (const v2::LastDesc*)dlast);
+        break;
+      }
+      hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq2 + o), lay);
+      hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNm + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dmt + o));
+      if (qr_batch(st, dq2 + o, dims, lay, force_tall) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
+      hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats);
+      hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNc + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dcr + o));
+    }
+    hipLaunchKernelGGL(v2::k_normalize_out, dim3(P), dim3(256), 0, st, (const v2::NormDesc*)dnrm, c->d_stats);
+    HIPCHK(c, hipGetLastError());
+    // the host vectors of this block must outlive the copies: they were synchronised above
+    *did_sweep2 = 1;
+  }
   return MPBP_OK;
 }

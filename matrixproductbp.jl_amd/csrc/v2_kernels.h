@@ -702,6 +702,160 @@ __global__ void __launch_bounds__(256) k_lf_write(const QrProb* probs, const LfD
   }
 }
 
+// ==================================================================================================================
+// The truncating sweep (sweep 2 of engine.h: the orthogonalize_left!(svd_trunc) half of compress!) in grid-level form,
+// for the SVDTrunc rules whose kept rank follows from the dimensions (TruncBond, TruncBondMax), so that the host can
+// plan every time step.  Per step: k_build_E, k_gemm (N1), k_gemm (N2), k_absmax + k_scale (the max-abs rescale that the
+// reference folds into z), k_zero_pads + k_gemm (M_t^T = Lf^T N_t^T), the batched QR above, k_svd_trunc (one-sided
+// Jacobi on the transposed triangular factor, truncation, new core), k_gemm (carry C_t = U^T N_t).
+// ==================================================================================================================
+struct ScaleDesc { double* A; int64_t n; double* mx; double* logc; double* mx_next; };   // mx_next: the slot of the next step, zeroed here
+
+__global__ void __launch_bounds__(256) k_absmax(const ScaleDesc* descs) {
+  const ScaleDesc D = descs[blockIdx.y];
+  const gdbl* A = (const gdbl*)D.A;
+  double mx = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < D.n; i += (int64_t)gridDim.x * 256) mx = fmax(mx, fabs(A[i]));
+  mx = wave_max(mx);
+  // NaN compares false everywhere: flag it through the bit pattern of +inf so that k_scale sees a non-finite maximum
+  if ((threadIdx.x & 63) == 0) {
+    if (!(mx == mx)) mx = __builtin_inf();
+    if (mx > 0.0) atomicMax((unsigned long long*)D.mx, (unsigned long long)__double_as_longlong(mx));
+  }
+}
+__global__ void __launch_bounds__(256) k_scale(const ScaleDesc* descs, EngStats* stats) {
+  const ScaleDesc D = descs[blockIdx.y];
+  gdbl* A = (gdbl*)D.A;
+  const double mx = *D.mx;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *D.mx_next = 0.0;
+  if (!(mx == mx) || isinf(mx)) { if (blockIdx.x == 0 && threadIdx.x == 0) stats->nan_flag = 1; return; }
+  if (!(mx > 0.0)) return;
+  const double inv = 1.0 / mx;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < D.n; i += (int64_t)gridDim.x * 256) A[i] *= inv;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *D.logc += log(mx);
+}
+
+struct SvdDesc {
+  const double* Mt; double* JA; double* U; double* core; int32_t* obond;   // obond: the output train's bond table
+  int32_t ldM, r1, Rr, kc, kp, t, L, kind, mprime, cap_out;
+};
+__device__ __forceinline__ void atomic_max_pos(unsigned long long* addr, double v) { atomicMax(addr, (unsigned long long)__double_as_longlong(v)); }
+
+// grid (nprob), 512 threads; dynamic LDS: 32 + Rr doubles + Rr ints
+__global__ void __launch_bounds__(512) k_svd_trunc(const SvdDesc* descs, EngStats* stats) {
+  const SvdDesc D = descs[blockIdx.x];
+  extern __shared__ __attribute__((aligned(16))) double dyn_[];
+  ldbl* red = (ldbl*)dyn_;
+  ldbl* sig = red + 32;
+  typedef __attribute__((address_space(3))) int lint_t;
+  lint_t* ord = (lint_t*)(sig + D.Rr);
+  const int tid = threadIdx.x;
+  const int Rr = D.Rr, r1 = D.r1, kc = D.kc;
+  const int k2 = min(r1, Rr);
+  const int ldJ = Rr | 1;
+  const gdbl* Mt = (const gdbl*)D.Mt;
+  gdbl* JA = (gdbl*)D.JA;
+  double fro2 = 0.0;
+  for (int idx = tid; idx < k2 * Rr; idx += 512) {
+    const int r = idx % Rr, c = idx / Rr;            // JA[r, c] = R2[c, r]
+    const double v = (r >= c) ? Mt[c + (int64_t)D.ldM * r] : 0.0;
+    JA[r + (int64_t)ldJ * c] = v;
+    fro2 += v * v;
+  }
+  fro2 = wg_sum(fro2, red);
+  __syncthreads();
+  const int sw = jacobi_rsv(JA, ldJ, Rr, k2, nullptr, 0, red, ord, 60);
+  if (tid == 0) {
+    if (sw < 0) stats->jacobi_fail = 1;
+    atomicAdd(&stats->jac_sweeps, (unsigned long long)(sw < 0 ? 60 : sw));
+    atomicAdd(&stats->jac_calls, 1ULL);
+  }
+  const double nul2 = 1e-28 * fro2;
+  for (int c = tid; c < Rr; c += 512) sig[c] = 0.0;
+  __syncthreads();
+  for (int c = tid; c < k2; c += 512) {
+    double s = 0.0;
+    for (int r = 0; r < Rr; r++) { const double v = JA[r + (int64_t)ldJ * c]; s += v * v; }
+    const bool ok = s > nul2 && s > 0.0;
+    const double sg = ok ? sqrt(s) : 0.0, inv = ok ? 1.0 / sqrt(s) : 0.0;
+    for (int r = 0; r < Rr; r++) JA[r + (int64_t)ldJ * c] *= inv;
+    sig[c] = sg;
+  }
+  __syncthreads();
+  for (int c = tid; c < k2; c += 512) {
+    const double sc = sig[c];
+    int rank = 0;
+    for (int j = 0; j < k2; j++) { const double sj = sig[j]; rank += (sj > sc) || (sj == sc && j < c); }
+    ord[rank] = c;
+  }
+  __syncthreads();
+  const int len = min(Rr, r1);
+  int kp = min(len, D.mprime);
+  if (kp < 1) kp = 1;
+  if (kp > D.cap_out) { kp = D.cap_out; if (tid == 0) stats->capacity_flag = 1; }
+  // kp == D.kp by construction (the host planned the buffers with the same rule)
+  if (D.kind == MPBP_TRUNC_BOND_MAX && tid == 0) {
+    double tot = 0.0, dropped = 0.0;
+    for (int j = 0; j < len; j++) { const double s = sig[ord[j]]; tot += s * s; if (j >= kp) dropped += s * s; }
+    if (tot > 0.0) atomic_max_pos(&stats->maxerr_bits, sqrt(dropped / tot));
+  }
+  gdbl* oc = (gdbl*)D.core;
+  gdbl* U = (gdbl*)D.U;
+  for (int idx = tid; idx < Rr * kp; idx += 512) {
+    const int row = idx % Rr, k2i = idx / Rr;
+    const int k = row % kc, s = row / kc;
+    const double v = JA[row + (int64_t)ldJ * ord[k2i]];
+    oc[(int64_t)k + (int64_t)kc * (k2i + (int64_t)kp * s)] = v;       // core t: [kc, kp, s]
+    U[idx] = v;                                                        // sorted left singular vectors, ld Rr
+  }
+  if (tid == 0) {
+    D.obond[D.t + 1] = kp;
+    if (D.t == 0) { D.obond[0] = 1; D.obond[D.L] = 1; }
+  }
+}
+
+// last core of the truncating sweep: [kc, 1, s] = N_t[(k,s), 0]; grid (nprob)
+struct LastDesc { const double* Nt; double* core; int32_t* obond; int32_t Rr, L; };
+__global__ void __launch_bounds__(256) k_lastcore(const LastDesc* descs) {
+  const LastDesc D = descs[blockIdx.x];
+  for (int idx = threadIdx.x; idx < D.Rr; idx += 256) D.core[idx] = D.Nt[idx];
+  if (threadIdx.x == 0) { D.obond[0] = 1; D.obond[D.L] = 1; }
+}
+
+// normalize_eachmatrix! of the output train + its log z (engine.h tail); grid (nprob), 256 threads
+struct NormDesc {
+  double* out; const int32_t* obond; int64_t ostride; const double* logz1; const double* logz2; const double* logc; double* ologz;
+  int32_t sphys, L;
+};
+__global__ void __launch_bounds__(256) k_normalize_out(const NormDesc* descs, EngStats* stats) {
+  const NormDesc D = descs[blockIdx.x];
+  __shared__ double red_[8];
+  ldbl* red = (ldbl*)red_;
+  const int tid = threadIdx.x;
+  double logz = (D.logz1 ? *D.logz1 : 0.0) + (D.logz2 ? *D.logz2 : 0.0) - *D.logc;
+  for (int tp = 0; tp < D.L; tp++) {
+    const int n = D.obond[tp] * D.obond[tp + 1] * D.sphys;
+    gdbl* oc = (gdbl*)D.out + (int64_t)tp * D.ostride;
+    double mx = 0.0;
+    for (int idx = tid; idx < n; idx += 256) mx = fmax(mx, fabs(oc[idx]));
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (mx > 0.0 && isfinite(mx)) {
+      const double inv = 1.0 / mx;
+      for (int idx = tid; idx < n; idx += 256) oc[idx] *= inv;
+      logz -= log(mx);
+    }
+  }
+  if (tid == 0) {
+    *D.ologz = logz;
+    atomicAdd(&stats->n_compress, 1ULL);
+    if (!(logz == logz)) stats->nan_flag = 1;
+  }
+}
+
 // bond tables of both operands of every problem -> one contiguous buffer [nprob][2][L+1]; Lf_L = 1; grid (nprob)
 struct BondSrc { const int32_t* b1; const int32_t* b2; };
 __global__ void __launch_bounds__(64) k_gather_bonds(const BondSrc* src, int32_t* out, int L) {
