@@ -84,8 +84,15 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
         if (trail_nt == 1) hipLaunchKernelGGL(v2::k_trail4f<1>, dim3((ntile4 + 3) / 4, P), dim3(256), 0, st, d_probs, lay, jb);
         else hipLaunchKernelGGL(v2::k_trail4f<2>, dim3((ntile4 + 7) / 8, P), dim3(256), 0, st, d_probs, lay, jb);
       }
-      const int only_short = fused ? 1 : 0;
-      if (!fused || kmax_min - jb < 64) {
+      // few large problems: (16 tiles x row chunk) workgroups with the panels shared through LDS, two launches
+      const bool coop = !fused && npmax == 4 && ntile4 > 0 && !getenv("MPBP_DEBUG_NO_COOP_TRAIL");
+      if (coop) {
+        const dim3 gc((ntile4 + 15) / 16, nchunk, P);
+        hipLaunchKernelGGL(v2::k_trailW_coop, gc, dim3(512), 0, st, d_probs, lay, jb);
+        hipLaunchKernelGGL(v2::k_trailU_coop, gc, dim3(512), 0, st, d_probs, lay, jb);
+      }
+      const int only_short = (fused || coop) ? 1 : 0;
+      if ((!fused && !coop) || kmax_min - jb < 64) {
         const dim3 g((ntile_max + 3) / 4, nchunk, P);
         switch (npmax) {
           case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);

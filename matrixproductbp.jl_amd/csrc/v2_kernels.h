@@ -606,6 +606,218 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same two launches with the reflector panels shared through LDS (the scheme of wg::qr_trail4_coop, split at the
+// reduction over row chunks): a workgroup of 8 waves takes 16 tiles (two per wave) x one row chunk; every 32-row stage of
+// the four panels is loaded once by the workgroup into a double-buffered LDS tile (column stride 34 rows: conflict free
+// for both fragment shapes; heads in unit-lower-trapezoidal form), C goes HBM -> registers (one stage prefetched),
+// stage barriers order LDS only.  Problems with four full panels in the block; the others take k_trailW / k_trailU<NP>.
+// grid (ceil(ntile / 16), nchunk, nprob), 512 threads.
+// ------------------------------------------------------------------------------------------------------------------
+struct CoopStage {
+  const gdbl* vsrc; int sc, sr, spanel, scol;
+  __device__ __forceinline__ void init(const gdbl* Y, long ld, int jb) {
+    const int tid = threadIdx.x;
+    sc = tid >> 3; sr = tid & 7; spanel = sc >> 4; scol = sc & 15;
+    vsrc = Y + (long)(jb + sc) * ld + 4 * sr;
+  }
+  // rows [32 s, 32 s + 32) (absolute); panel p's diagonal block starts at row jb + 16 p
+  __device__ __forceinline__ d4 load(int s, int slast) const { return *reinterpret_cast<const gd4*>(vsrc + 32 * min(s, slast)); }
+  __device__ __forceinline__ void store(ldbl* Vs, int s, int jb, d4 v) const {
+    ldbl* dst = Vs + (s & 1) * QR_VS_STAGE + sc * QR_VS_LD + 4 * sr;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rp = 32 * s + 4 * sr + e - jb - 16 * spanel;
+      double a = v[e];
+      a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
+      v[e] = (rp >= 0) ? a : 0.0;
+    }
+    *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
+    *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
+  }
+};
+
+__global__ void __launch_bounds__(512) k_trailW_coop(const QrProb* probs, AuxLay lay, int jb) {
+  const QrProb P = probs[blockIdx.z];
+  if (P.kmax - jb < 64) return;
+  const int c0 = jb + 64;
+  const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
+  if (blockIdx.x * 16 >= ntile) return;
+  const int rows32 = (P.rows + 31) & ~31;
+  const int chunk = blockIdx.y;
+  const int s0 = max(chunk * CH, jb) >> 5, s1 = min((chunk + 1) * CH, rows32) >> 5;     // stages of this chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const gdbl* Y = (const gdbl*)P.Y;
+  gdbl* aux = (gdbl*)P.aux;
+  const long ld = P.ld;
+  __shared__ double vs_[2 * QR_VS_STAGE];
+  ldbl* Vs = (ldbl*)vs_;
+  const int tile = blockIdx.x * 16 + 2 * wave;
+  const int nt = max(0, min(2, ntile - tile));
+  const int cq0 = c0 + 16 * ((nt >= 1) ? tile : 0), cq1 = (nt >= 2) ? cq0 + 16 : cq0;
+  d4 w0[4][2];
+#pragma unroll
+  for (int p = 0; p < 4; p++) { w0[p][0] = d4{0, 0, 0, 0}; w0[p][1] = d4{0, 0, 0, 0}; }
+  if (s0 < s1) {
+    CoopStage st; st.init(Y, ld, jb);
+    const gdbl* c0p = Y + (long)(cq0 + l15) * ld + 4 * g;
+    const gdbl* c1p = Y + (long)(cq1 + l15) * ld + 4 * g;
+    d4 vreg = st.load(s0, s1 - 1);
+    st.store(Vs, s0, jb, vreg);
+    d4 cc[2][2];
+    cc[0][0] = *reinterpret_cast<const gd4*>(c0p + 32 * s0); cc[0][1] = *reinterpret_cast<const gd4*>(c0p + 32 * s0 + 16);
+    cc[1][0] = *reinterpret_cast<const gd4*>(c1p + 32 * s0); cc[1][1] = *reinterpret_cast<const gd4*>(c1p + 32 * s0 + 16);
+    for (int s = s0; s < s1; s++) {
+      vreg = st.load(s + 1, s1 - 1);
+      const int sn = min(s + 1, s1 - 1);
+      d4 cn[2][2];
+      cn[0][0] = *reinterpret_cast<const gd4*>(c0p + 32 * sn); cn[0][1] = *reinterpret_cast<const gd4*>(c0p + 32 * sn + 16);
+      cn[1][0] = *reinterpret_cast<const gd4*>(c1p + 32 * sn); cn[1][1] = *reinterpret_cast<const gd4*>(c1p + 32 * sn + 16);
+      lds_barrier();
+      const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
+      if (nt > 0) {
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            const ldbl* vp = vb + (16 * p + l15) * QR_VS_LD + 16 * rb + 4 * g;
+            const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
+            const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
+            if (nt > 1) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) { w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]); w0[p][1] = mfma(v4[e], cc[1][rb][e], w0[p][1]); }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; e++) w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]);
+            }
+          }
+        }
+      }
+      st.store(Vs, s + 1, jb, vreg);
+      cc[0][0] = cn[0][0]; cc[0][1] = cn[0][1]; cc[1][0] = cn[1][0]; cc[1][1] = cn[1][1];
+    }
+  }
+  // partial products of this chunk, in the slot layout k_trailU reads (row sub-chunk 0 of 4)
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (q < nt) {
+      gdbl* w0o = aux + lay.w0 + ((long)(tile + q) * (lay.nchunk * 4) + chunk * 4) * 1024;
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) w0o[256 * p + (g + 4 * r) + 16 * l15] = w0[p][q][r];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512) k_trailU_coop(const QrProb* probs, AuxLay lay, int jb) {
+  const QrProb P = probs[blockIdx.z];
+  if (P.kmax - jb < 64) return;
+  const int c0 = jb + 64;
+  const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
+  if (blockIdx.x * 16 >= ntile) return;
+  const int rows32 = (P.rows + 31) & ~31;
+  const int chunk = blockIdx.y;
+  const int s0 = max(chunk * CH, jb) >> 5, s1 = min((chunk + 1) * CH, rows32) >> 5;
+  if (s0 >= s1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  gdbl* Y = (gdbl*)P.Y;
+  const gdbl* aux = (const gdbl*)P.aux;
+  const long ld = P.ld;
+  __shared__ double sh_[10 * 256 + 2 * QR_VS_STAGE];
+  ldbl* Tq = (ldbl*)sh_;
+  ldbl* Sq = Tq + 4 * 256;
+  ldbl* Vs = Sq + 6 * 256;
+  for (int i = tid; i < 4 * 256; i += 512) Tq[i] = aux[lay.T + i];
+  for (int i = tid; i < 6 * 256; i += 512) Sq[i] = aux[lay.S + i];
+  const int tile = blockIdx.x * 16 + 2 * wave;
+  const int nt = max(0, min(2, ntile - tile));
+  const int tq0 = (nt >= 1) ? tile : 0, tq1 = (nt >= 2) ? tile + 1 : tq0;
+  const int cq0 = c0 + 16 * tq0, cq1 = c0 + 16 * tq1;
+  CoopStage st; st.init(Y, ld, jb);
+  d4 vreg = st.load(s0, s1 - 1);
+  __syncthreads();                                           // T, S are in LDS
+  st.store(Vs, s0, jb, vreg);
+  // W of this wave's tiles: partial products of every chunk in a fixed order, then the recurrence
+  const int cfirst = jb / CH, clast = (rows32 - 1) / CH;
+  d4 w[4][2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int tl = q ? tq1 : tq0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      d4 t = d4{0, 0, 0, 0};
+      for (int cc = cfirst; cc <= clast; cc++) {
+        const gdbl* w0 = aux + lay.w0 + ((long)tl * (lay.nchunk * 4) + cc * 4) * 1024 + 256 * p;
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[r] += w0[(g + 4 * r) + 16 * l15];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (r < p) {
+          const ldbl* S = Sq + (p * (p - 1) / 2 + r) * 256;
+#pragma unroll
+          for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
+        }
+      }
+      d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) o = mfma(Tq[p * 256 + (4 * s + g) + 16 * l15], t[s], o);
+      w[p][q] = o;
+    }
+  }
+  gdbl* cp0 = Y + (long)(cq0 + g) * ld + 2 * l15;
+  gdbl* cp1 = Y + (long)(cq1 + g) * ld + 2 * l15;
+  d2 cc[2][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    cc[0][r] = *reinterpret_cast<const gd2*>(cp0 + (long)(4 * r) * ld + 32 * s0);
+    cc[1][r] = *reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld + 32 * s0);
+  }
+  for (int s = s0; s < s1; s++) {
+    vreg = st.load(s + 1, s1 - 1);
+    const int sn = min(s + 1, s1 - 1);
+    d2 cn[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      cn[0][r] = *reinterpret_cast<const gd2*>(cp0 + (long)(4 * r) * ld + 32 * sn);
+      cn[1][r] = *reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld + 32 * sn);
+    }
+    lds_barrier();
+    const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
+    if (nt > 0) {
+      d4 acc[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+          const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * QR_VS_LD + 2 * l15);
+          if (nt > 1) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) { acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]); acc[1][e] = mfma(-w[p][1][s2], v[e], acc[1][e]); }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 2; e++) acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]);
+          }
+        }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        *reinterpret_cast<gd2*>(cp0 + (long)(4 * r) * ld + 32 * s) = d2{acc[0][0][r], acc[0][1][r]};
+        if (nt > 1) *reinterpret_cast<gd2*>(cp1 + (long)(4 * r) * ld + 32 * s) = d2{acc[1][0][r], acc[1][1][r]};
+      }
+    }
+    st.store(Vs, s + 1, jb, vreg);
+#pragma unroll
+    for (int r = 0; r < 4; r++) { cc[0][r] = cn[0][r]; cc[1][r] = cn[1][r]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Batched contraction O = S X with separable two-level index maps (the Y1 / Y2 assembly of engine.h, every wave of
 // the grid taking 16-column tiles of the output).  grid (nwg, ngemm), 512 threads.
 // ------------------------------------------------------------------------------------------------------------------
