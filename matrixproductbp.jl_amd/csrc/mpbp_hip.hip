@@ -540,6 +540,11 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
       }
       // the triangular factors live in c->v2arena until sweep 2 has consumed them
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      {
+        int herr = 0;
+        HIPCHK(c, hipMemcpy(&herr, c->d_counter + 8, sizeof(int), hipMemcpyDeviceToHost));
+        if (herr) return c->fail(MPBP_EHIP, "batched gauge sweep: an arrival counter of the cooperative panel kernel timed out (workgroups not co-resident?); rerun with MPBP_DEBUG_NO_COOP_PANEL=1");
+      }
       done += nd;
     }
   }

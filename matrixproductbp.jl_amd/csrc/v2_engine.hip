@@ -23,7 +23,7 @@ struct QrDims { int rows, cols, kmax; };
 // Launch sequence of one R-only QR over a batch whose dimensions `dims` are known on the host.
 // d_probs: device array of v2::QrProb (same order as dims).  force_tall: column-step panels even when they would fit.
 int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims>& dims, const v2::AuxLay& lay,
-             bool force_tall) {
+             bool force_tall, int* coop_err = nullptr, int coop_max_wgs = 128) {
   const int P = (int)dims.size();
   if (P == 0) return 0;
   int kmax_max = 0, kmax_min = 1 << 30, rows32_max = 0, cols_max = 0;
@@ -64,8 +64,12 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
         }
       }
       if (tall) {
-        for (int jj = 0; jj <= 16; jj++)
-          hipLaunchKernelGGL(v2::k_colstep, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jp, jj, p);
+        // every row-chunk workgroup resident at once: one launch with arrival counters; else one launch per column
+        if (coop_err && (int64_t)nchunk * P <= coop_max_wgs && !getenv("MPBP_DEBUG_NO_COOP_PANEL"))
+          hipLaunchKernelGGL(v2::k_colsteps_coop, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jp, p, coop_err);
+        else
+          for (int jj = 0; jj <= 16; jj++)
+            hipLaunchKernelGGL(v2::k_colstep, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jp, jj, p);
         hipLaunchKernelGGL(v2::k_gram, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jb, p);
         hipLaunchKernelGGL(v2::k_build_T, dim3(P), dim3(64), 0, st, d_probs, lay, jb, p);
       } else {
@@ -146,10 +150,15 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
   ST2CHK(hipMemcpy(dP, hp.data(), sizeof(v2::QrProb) * nprob, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, 0);
-  const int rc = qr_batch(0, dP, dims, lay, force_tall != 0);
+  int* dErr = nullptr;
+  ST2CHK(hipMalloc(&dErr, sizeof(int)));
+  ST2CHK(hipMemset(dErr, 0, sizeof(int)));
+  const int rc = qr_batch(0, dP, dims, lay, force_tall != 0, dErr);
   hipEventRecord(e1, 0);
   ST2CHK(hipDeviceSynchronize());
   if (rc != 0) { g_create_error = "qr_batch launch failed"; return MPBP_EHIP; }
+  { int herr = 0; ST2CHK(hipMemcpy(&herr, dErr, sizeof(int), hipMemcpyDeviceToHost)); hipFree(dErr);
+    if (herr) { g_create_error = "cooperative panel: an arrival counter timed out"; return MPBP_EHIP; } }
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   if (ms_out) *ms_out = ms;
   hipEventDestroy(e0); hipEventDestroy(e1);
@@ -366,6 +375,9 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     HIPCHK(c, hipMemcpyAsync(bf[i].lfoff, htab.data() + (size_t)i * (L + 1) * 12, (size_t)(L + 1) * 12, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));     // the host vectors go out of scope below only after the loop, but keep it simple
   hipLaunchKernelGGL(v2::k_set_one, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SetOne*)done, P);
+  for (int i = 0; i < P; i++) HIPCHK(c, hipMemsetAsync(bf[i].aux, 0, sizeof(double) * (size_t)lay.part, st));   // counters, T/S, slots
+  int* coop_err = c->d_counter + 8;
+  HIPCHK(c, hipMemsetAsync(coop_err, 0, sizeof(int), st));
   const bool force_tall = [] { const char* e = getenv("MPBP_DEBUG_FORCE_TALL"); return e && e[0] == '1'; }();
   // ---- the time steps
   std::vector<QrDims> dims(P);
@@ -383,7 +395,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN1 + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dg1 + o));
     hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
     hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN2 + 127) / 128), P * q), dim3(512), 0, st, (const v2::GemmDesc*)(dg2 + o * q));
-    if (qr_batch(st, dq + o, dims, lay, force_tall) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (qr_batch(st, dq + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
     const int gw = std::min(256, std::max(1, (colsm + 3) / 4));
     hipLaunchKernelGGL(v2::k_maxabs, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
     hipLaunchKernelGGL(v2::k_lf_write, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), (const v2::LfDesc*)(dl + o), lay);
@@ -508,7 +520,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       }
       hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq2 + o), lay);
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNm + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dmt + o));
-      if (qr_batch(st, dq2 + o, dims, lay, force_tall) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
+      if (qr_batch(st, dq2 + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
       hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats);
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNc + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dcr + o));
     }

@@ -36,7 +36,7 @@ struct QrProb {
 // offsets (doubles) into QrProb::aux - the same for every problem of a batch
 struct AuxLay {
   int32_t nchunk;                 // partial slots per tile in w0 = nchunk * 4 (row sub-chunks of the in-block updates)
-  int64_t T, S, tau, piv, mx, part, gram, w0;
+  int64_t T, S, tau, piv, mx, bar, part, gram, w0;
 };
 __host__ __device__ inline AuxLay make_auxlay(int nchunk, int ntile) {
   AuxLay a; a.nchunk = nchunk;
@@ -46,6 +46,7 @@ __host__ __device__ inline AuxLay make_auxlay(int nchunk, int ntile) {
   a.tau = o; o += 64;
   a.piv = o; o += 256;
   a.mx = o; o += 16;
+  a.bar = o; o += 16;            // 17 int32 arrival counters of the cooperative column steps (+ padding)
   a.part = o; o += (int64_t)nchunk * 256;
   a.gram = o; o += (int64_t)nchunk * 4 * 256;
   a.w0 = o; o += (int64_t)ntile * nchunk * 4 * 4 * 256;
@@ -53,7 +54,7 @@ __host__ __device__ inline AuxLay make_auxlay(int nchunk, int ntile) {
   return a;
 }
 __host__ __device__ inline int64_t auxlay_doubles(int nchunk, int ntile) {
-  return 4 * 256 + 6 * 256 + 64 + 256 + 16 + (int64_t)nchunk * 256 + (int64_t)nchunk * 1024 + (int64_t)ntile * nchunk * 4096;
+  return 4 * 256 + 6 * 256 + 64 + 256 + 16 + 16 + (int64_t)nchunk * 256 + (int64_t)nchunk * 1024 + (int64_t)ntile * nchunk * 4096;
 }
 
 __device__ __forceinline__ double sel16(const double (&v)[16], int j) {
@@ -172,6 +173,125 @@ __global__ void __launch_bounds__(512) k_colstep(const QrProb* probs, AuxLay lay
 #pragma unroll
       for (int w = 0; w < 8; w++) s += red[w * 16 + tid];
       aux[lay.part + ((long)chunk * 16 + jj) * 16 + tid] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The 17 column steps of a panel in ONE launch, for batches small enough that every participating workgroup is
+// resident at once (host: nchunk * nprob <= 3/4 of the CUs; one 512-thread workgroup of this kernel fits per CU): each workgroup keeps its 2048 x 16 slice of the panel in
+// registers for the whole factorisation (one load, one store instead of 17 of each) and the column steps are separated by
+// an arrival counter per (problem, column) instead of kernel boundaries.  Hand-off protocol as prescribed for gfx950
+// (MI355X_MICROARCH.md, inter-workgroup visibility): stores -> s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: agent
+// release fence, s_waitcnt vmcnt(0), relaxed agent atomic add; consumer: relaxed polls with s_sleep -> ONE agent acquire
+// fence -> s_waitcnt vmcnt(0) -> workgroup barrier -> plain loads.  Every spin is bounded: after ~2^21 polls the
+// workgroup raises *err and leaves (the host reports MPBP_EHIP) - the grid always drains.
+// Counters are zeroed by k_build_T (the launch that follows every panel).  grid (nchunk, nprob), 512 threads.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_colsteps_coop(const QrProb* probs, AuxLay lay, int jp, int pidx, int* err) {
+  const QrProb P = probs[blockIdx.y];
+  if (jp >= P.kmax) return;
+  const int chunk = blockIdx.x;
+  const int rows32 = (P.rows + 31) & ~31;
+  const int cfirst = jp / CH, clast = (rows32 - 1) / CH;
+  if (chunk < cfirst || chunk > clast) return;
+  const int nwg = clast - cfirst + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  gdbl* Y = (gdbl*)P.Y;
+  gdbl* aux = (gdbl*)P.aux;
+  int* bar = (int*)(P.aux + lay.bar);
+  const long ld = P.ld;
+  __shared__ double red_[8 * 16];
+  ldbl* red = (ldbl*)red_;
+  double Pn[4][16];
+  bool rv[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int r = chunk * CH + tid + 512 * s;
+    rv[s] = r < rows32 && r >= jp;
+    const int rc = rv[s] ? r : jp;
+#pragma unroll
+    for (int c = 0; c < 16; c++) { const double v = Y[(long)(jp + c) * ld + rc]; Pn[s][c] = rv[s] ? v : 0.0; }
+  }
+  for (int jj = 0; jj <= 16; jj++) {
+    if (jj >= 1) {
+      const int j = jj - 1;
+      double tot[16], rowv[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) tot[c] = 0.0;
+      for (int cc = cfirst; cc <= clast; cc++) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) tot[c] += aux[lay.part + ((long)cc * 16 + j) * 16 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) rowv[c] = aux[lay.piv + j * 16 + c];
+      const double ss = sel16(tot, j), alpha = sel16(rowv, j);
+      double beta, tj, scale;
+      larfg(alpha, ss, beta, tj, scale);
+      double tw[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) tw[c] = (c > j) ? tj * (rowv[c] + scale * tot[c]) : 0.0;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int r = chunk * CH + tid + 512 * s;
+        const bool below = rv[s] && r > jp + j, pivot = r == jp + j;
+        const double xj = sel16(Pn[s], j);
+        const double v = below ? xj * scale : (pivot ? 1.0 : 0.0);
+        const double nxj = below ? v : (pivot ? beta : xj);
+#pragma unroll
+        for (int c = 0; c < 16; c++) Pn[s][c] = (c == j) ? nxj : Pn[s][c] - tw[c] * v;
+      }
+      if (chunk == cfirst && tid == 0) aux[lay.tau + pidx * 16 + j] = tj;
+    }
+    if (jj == 16) break;
+    double vals[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) vals[c] = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int r = chunk * CH + tid + 512 * s;
+      const bool below = rv[s] && r > jp + jj;
+      const double x = below ? sel16(Pn[s], jj) : 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; c++) vals[c] += x * Pn[s][c];
+      if (r == jp + jj) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) aux[lay.piv + jj * 16 + c] = Pn[s][c];
+      }
+    }
+    int idx;
+    const double wsum = wave_sum16(vals, lane, idx);
+    if ((lane & 3) == 0) red[wave * 16 + idx] = wsum;
+    __syncthreads();
+    if (tid < 16) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) s += red[w * 16 + tid];
+      aux[lay.part + ((long)chunk * 16 + jj) * 16 + tid] = s;
+    }
+    // ---- arrival: every store of this workgroup is out, then lane 0 publishes and waits for the others
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&bar[jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (__hip_atomic_load(&bar[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
+        if (++spins > (1 << 21)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int r = chunk * CH + tid + 512 * s;
+    if (rv[s]) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) Y[(long)(jp + c) * ld + r] = Pn[s][c];
     }
   }
 }
@@ -436,6 +556,7 @@ __global__ void __launch_bounds__(64) k_build_T(const QrProb* probs, AuxLay lay,
   __syncthreads();
   qr_T_from_gram(G, tau, 16, Ts);
   for (int idx = tid; idx < 256; idx += 64) aux[lay.T + pidx * 256 + idx] = Ts[idx];
+  if (tid < 32) ((int*)(P.aux + lay.bar))[tid] = 0;          // arrival counters of the next cooperative panel
 }
 
 // ------------------------------------------------------------------------------------------------------------------
