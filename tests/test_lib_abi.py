@@ -29,3 +29,26 @@ def test_create_reports_errors_without_aborting():
     rc = lib.mpbp_create(C.byref(h), C.byref(d))
     assert rc == -1
     assert b"invalid descriptor" in lib.mpbp_last_error(None)
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """Sizes and key field offsets of the ABI structs as a C compiler sees include/mpbp_hip.h against the ctypes mirror
+    (a drifted struct would silently shift `periodic` / `stream` / the stats fields)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no C compiler")
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mpbp_hip.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mpbp_desc), sizeof(mpbp_trunc), sizeof(mpbp_stats),\n'
+                   '         sizeof(mpbp_layout), offsetof(mpbp_desc, periodic), offsetof(mpbp_desc, stream),\n'
+                   '         offsetof(mpbp_stats, jacobi_calls));\n  return 0;\n}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    L = mpbp_amd._lib
+    want = [C.sizeof(L.Desc), C.sizeof(L.Trunc), C.sizeof(L.Stats), C.sizeof(L.Layout), L.Desc.periodic.offset,
+            L.Desc.stream.offset, L.Stats.jacobi_calls.offset]
+    assert got == want
