@@ -293,3 +293,35 @@ def test_baseline_config0_glauber_3node_path_exact():
         p, Z = exact_prob(bp)
     assert np.abs(np.array(O.beliefs(bp)) - np.array(exact_marginals(bp, p))).max() < 1e-8
     assert abs(np.exp(-O.bethe_free_energy(bp)) - Z) / Z < 1e-8
+
+
+def test_device_algorithm_equals_reference_compress_with_binding_truncation():
+    """The R-only-QR gauge sweep + truncating SVD of M_t = N_t Lf_{t+1} (what the HIP engine computes,
+    oracle/device_algorithm.py) gives the same truncated FUNCTION as the reference's two SVD sweeps (`compress!` inside
+    `op`, recursive_bp_factor.jl:127) when the cap binds: the two output trains differ by a gauge only."""
+    from oracle import mpbp as O
+    from oracle.device_algorithm import op_kron_compress_qr
+    from oracle.factors import SISFactor, HomogeneousGlauberFactor
+    from oracle.tensor_trains import TensorTrain, TruncBond, TruncBondMax, TruncThresh, evaluate
+    rng = np.random.default_rng(7)
+    T = 5
+    for (w, d1, d2) in [(SISFactor(0.2, 0.1), 1, 1), (HomogeneousGlauberFactor(0.4, 0.1, 1.0), 2, 1)]:
+        wi = [w] * (T + 1)
+        prof = [1, 3, 5, 5, 4, 2, 1]
+
+        def rand_train(d):
+            ny = w.nstates(d)
+            return TensorTrain([rng.random((prof[t], prof[t + 1], ny, 2)) + 0.05 for t in range(T + 1)], logz=0.3 * d)
+        for trunc_f in (lambda: TruncBond(4), lambda: TruncBondMax(3), lambda: TruncThresh(1e-3)):
+            A, B = rand_train(d1), rand_train(d2)
+            ta, tb = trunc_f(), trunc_f()
+            ref, _ = O.op_kron_compress(wi, (A.copy(), d1), (B.copy(), d2), T, ta)
+            dev, _ = op_kron_compress_qr(wi, (A.copy(), d1), (B.copy(), d2), T, tb)
+            assert ref.bonds == dev.bonds
+            if isinstance(ta, TruncBondMax):
+                assert abs(ta.maxerr - tb.maxerr) < 1e-12 and ta.maxerr > 1e-6       # the cap really binds
+            ny = w.nstates(d1 + d2)
+            for _ in range(40):
+                x = [(int(rng.integers(ny)), int(rng.integers(2))) for _ in range(T + 1)]
+                ra, rb = evaluate(ref, x), evaluate(dev, x)
+                assert abs(ra - rb) <= 1e-11 * max(abs(ra), 1e-300) + 1e-14
