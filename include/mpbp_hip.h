@@ -214,6 +214,10 @@ int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, const double* 
                       double* V);
 /* nprob independent rows x cols matrices (A: [nprob][rows x cols] column-major) through the grid-level batched QR of
  * the gauge sweep (csrc/v2_kernels.h); R: [nprob][min(rows,cols) x cols]; force_tall: column-step panels always. */
+/* the multi-launch (grid-level) one-sided Jacobi of the batched truncating sweep on one m x n matrix (n <= m <= 1024):
+ * column norms after convergence and the number of sweeps (-1: not converged) */
+int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps,
+                              int32_t* sweeps);
 int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t cols, int32_t nprob, int32_t force_tall,
                              const double* A, double* R, double* ms_out);
 

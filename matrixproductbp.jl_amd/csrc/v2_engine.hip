@@ -171,6 +171,37 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
   return MPBP_OK;
 }
 
+// self test of the multi-launch Jacobi (k_jac_round / k_jac_check): A [m x n] (ld m|1 inside) -> column norms after
+// convergence (= singular values, unsorted) and the number of sweeps (-1: not converged within maxsweeps)
+extern "C" int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps, int32_t* sweeps) {
+  ST2CHK(hipSetDevice(device));
+  if (m < 1 || n < 1 || n > m || m > 1024) { g_create_error = "need 1 <= n <= m <= 1024"; return MPBP_EINVAL; }
+  const int ldJ = m | 1;
+  std::vector<double> JA((size_t)ldJ * n, 0.0);
+  double fro2 = 0.0;
+  for (int c = 0; c < n; c++) for (int r = 0; r < m; r++) { const double v = A[r + (size_t)m * c]; JA[r + (size_t)ldJ * c] = v; fro2 += v * v; }
+  double *dJA = nullptr, *dscal = nullptr; v2::SvdDesc* dd = nullptr;
+  ST2CHK(hipMalloc(&dJA, sizeof(double) * JA.size())); ST2CHK(hipMalloc(&dscal, 512)); ST2CHK(hipMalloc(&dd, sizeof(v2::SvdDesc)));
+  ST2CHK(hipMemcpy(dJA, JA.data(), sizeof(double) * JA.size(), hipMemcpyHostToDevice));
+  double hs[8] = {0, 0, 0, fro2, 0, 0, (n < 2) ? 1.0 : 0.0, 0};
+  ST2CHK(hipMemcpy(dscal, hs, sizeof hs, hipMemcpyHostToDevice));
+  v2::SvdDesc D{};
+  D.JA = dJA; D.Rr = m; D.r1 = n; D.scal = dscal;
+  ST2CHK(hipMemcpy(dd, &D, sizeof D, hipMemcpyHostToDevice));
+  const int ne = (n + 1) & ~1;
+  for (int sw = 0; sw < maxsweeps; sw++) {
+    for (int r = 0; r < ne - 1; r++) hipLaunchKernelGGL(v2::k_jac_round, dim3((ne / 2 + 15) / 16, 1), dim3(512), 0, 0, (const v2::SvdDesc*)dd, r);
+    hipLaunchKernelGGL(v2::k_jac_check, dim3(1), dim3(64), 0, 0, (const v2::SvdDesc*)dd, 1);
+  }
+  ST2CHK(hipDeviceSynchronize());
+  ST2CHK(hipMemcpy(JA.data(), dJA, sizeof(double) * JA.size(), hipMemcpyDeviceToHost));
+  ST2CHK(hipMemcpy(hs, dscal, sizeof hs, hipMemcpyDeviceToHost));
+  for (int c = 0; c < n; c++) { double s = 0; for (int r = 0; r < m; r++) s += JA[r + (size_t)ldJ * c] * JA[r + (size_t)ldJ * c]; sigma[c] = sqrt(s); }
+  *sweeps = hs[6] != 0.0 ? (int)hs[5] : -1;
+  hipFree(dJA); hipFree(dscal); hipFree(dd);
+  return MPBP_OK;
+}
+
 // ================================================================================================
 // the batched gauge sweep
 // ================================================================================================
@@ -455,7 +486,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
         gmt[k] = m;
         q2[k] = v2::QrProb{bf[i].Mt, bf[i].aux, ldM, r1, Rr, std::min(r1, Rr)};
         sv[k] = v2::SvdDesc{bf[i].Mt, bf[i].JA, bf[i].U, Pr.out + (int64_t)t * Pr.ostride, Pr.obond,
-                            ldM, r1, Rr, kc, kp, t, L, trunc2->kind, trunc2->mprime, Pr.cap_out};
+                            ldM, r1, Rr, kc, kp, t, L, trunc2->kind, trunc2->mprime, Pr.cap_out, bf[i].scal};
         v2::GemmDesc cr{};
         cr.S = bf[i].U; cr.X = bf[i].Nt; cr.O = Cnew;
         cr.M = kp; cr.N = (int)Bn; cr.K = Rr;
@@ -489,6 +520,8 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     hipLaunchKernelGGL(v2::k_set_one, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SetOne*)done2, P);
     int rrm = 1;
     for (int i = 0; i < P; i++) rrm = std::max(rrm, plan[i].rr_max);
+    const int jac_grid_sweeps = [] { const char* e = getenv("MPBP_JACOBI_GRID_SWEEPS"); return e ? atoi(e) : 60; }();
+    const int jac_grid_min = [] { const char* e = getenv("MPBP_JACOBI_GRID_MIN"); return e ? atoi(e) : 384; }();
     const size_t svd_lds = sizeof(double) * (32 + (size_t)rrm + (rrm + 1) / 2 + 4);
     HIPCHK(c, hipFuncSetAttribute((const void*)v2::k_svd_trunc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)svd_lds));
     for (int t = 0; t < L; t++) {
@@ -521,7 +554,32 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq2 + o), lay);
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNm + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dmt + o));
       if (qr_batch(st, dq2 + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
-      hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats);
+      // the SVD of the triangular factor: inside one workgroup, or - factors of several hundred columns - as rounds of
+      // rotations over the grid (659 launches per sweep at 660 columns: 20+ workgroups rotate at once, a one-workgroup
+      // tournament of that size takes 0.3 s per time step)
+      int rrt = 1, k2t = 1;
+      for (int i = 0; i < P; i++) { const int Rr = plan[i].kc[t] * probs[i].ny * q; rrt = std::max(rrt, Rr); k2t = std::max(k2t, std::min(Rr, plan[i].rdim[t + 1])); }
+      const bool jgrid = rrt <= 1024 && k2t >= jac_grid_min;
+      if (!jgrid) hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 0);
+      else {
+        hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 1);
+        const int ne = (k2t + 1) & ~1;
+        // up to 60 sweeps, as the one-workgroup form allows; the host looks at the convergence flags every 4 sweeps
+        // (one 4-byte copy) so that the ~6-10 sweeps of the usual case are not followed by 50 sweeps of empty launches
+        for (int sweep = 0; sweep < jac_grid_sweeps; sweep++) {
+          for (int r = 0; r < ne - 1; r++)
+            hipLaunchKernelGGL(v2::k_jac_round, dim3((ne / 2 + 15) / 16, P), dim3(512), 0, st, (const v2::SvdDesc*)(dsv + o), r);
+          hipLaunchKernelGGL(v2::k_jac_check, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SvdDesc*)(dsv + o), P);
+          if ((sweep & 3) == 3) {
+            int pending = 0;
+            hipLaunchKernelGGL(v2::k_jac_pending, dim3(1), dim3(256), 0, st, (const v2::SvdDesc*)(dsv + o), P, c->d_counter + 9);
+            HIPCHK(c, hipMemcpyAsync(&pending, c->d_counter + 9, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (pending == 0) break;
+          }
+        }
+        hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 2);
+      }
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNc + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dcr + o));
     }
     hipLaunchKernelGGL(v2::k_normalize_out, dim3(P), dim3(256), 0, st, (const v2::NormDesc*)dnrm, c->d_stats);

@@ -1071,11 +1071,14 @@ __global__ void __launch_bounds__(256) k_scale(const ScaleDesc* descs, EngStats*
 struct SvdDesc {
   const double* Mt; double* JA; double* U; double* core; int32_t* obond;   // obond: the output train's bond table
   int32_t ldM, r1, Rr, kc, kp, t, L, kind, mprime, cap_out;
+  double* scal;    // per-problem scalars of the multi-launch Jacobi: [3] ||R||_F^2, [4] worst cos^2 of the sweep (bits), [5] sweeps, [6] done
 };
 __device__ __forceinline__ void atomic_max_pos(unsigned long long* addr, double v) { atomicMax(addr, (unsigned long long)__double_as_longlong(v)); }
 
 // grid (nprob), 512 threads; dynamic LDS: 32 + Rr doubles + Rr ints
-__global__ void __launch_bounds__(512) k_svd_trunc(const SvdDesc* descs, EngStats* stats) {
+// mode 0: everything in one launch (Jacobi inside the workgroup); 1: build JA only (the Jacobi then runs as k_jac_round /
+// k_jac_check launches over the grid); 2: everything after the Jacobi
+__global__ void __launch_bounds__(512) k_svd_trunc(const SvdDesc* descs, EngStats* stats, int mode) {
   const SvdDesc D = descs[blockIdx.x];
   extern __shared__ __attribute__((aligned(16))) double dyn_[];
   ldbl* red = (ldbl*)dyn_;
@@ -1089,15 +1092,23 @@ __global__ void __launch_bounds__(512) k_svd_trunc(const SvdDesc* descs, EngStat
   const gdbl* Mt = (const gdbl*)D.Mt;
   gdbl* JA = (gdbl*)D.JA;
   double fro2 = 0.0;
-  for (int idx = tid; idx < k2 * Rr; idx += 512) {
-    const int r = idx % Rr, c = idx / Rr;            // JA[r, c] = R2[c, r]
-    const double v = (r >= c) ? Mt[c + (int64_t)D.ldM * r] : 0.0;
-    JA[r + (int64_t)ldJ * c] = v;
-    fro2 += v * v;
+  if (mode != 2) {
+    for (int idx = tid; idx < k2 * Rr; idx += 512) {
+      const int r = idx % Rr, c = idx / Rr;            // JA[r, c] = R2[c, r]
+      const double v = (r >= c) ? Mt[c + (int64_t)D.ldM * r] : 0.0;
+      JA[r + (int64_t)ldJ * c] = v;
+      fro2 += v * v;
+    }
+    fro2 = wg_sum(fro2, red);
+    __syncthreads();
   }
-  fro2 = wg_sum(fro2, red);
-  __syncthreads();
-  const int sw = jacobi_rsv(JA, ldJ, Rr, k2, nullptr, 0, red, ord, 60);
+  if (mode == 1) {
+    if (tid == 0) { D.scal[3] = fro2; D.scal[4] = 0.0; D.scal[5] = 0.0; D.scal[6] = (k2 < 2) ? 1.0 : 0.0; }
+    return;
+  }
+  int sw;
+  if (mode == 0) sw = jacobi_rsv(JA, ldJ, Rr, k2, nullptr, 0, red, ord, 60);
+  else { fro2 = D.scal[3]; sw = (D.scal[6] != 0.0) ? (int)D.scal[5] : -1; }
   if (tid == 0) {
     if (sw < 0) stats->jacobi_fail = 1;
     atomicAdd(&stats->jac_sweeps, (unsigned long long)(sw < 0 ? 60 : sw));
@@ -1145,6 +1156,77 @@ __global__ void __launch_bounds__(512) k_svd_trunc(const SvdDesc* descs, EngStat
     D.obond[D.t + 1] = kp;
     if (D.t == 0) { D.obond[0] = 1; D.obond[D.L] = 1; }
   }
+}
+
+// One round of the round-robin tournament of the one-sided Jacobi (wg::jacobi_rsv's rotations, thresholds and pairing)
+// over the grid, for factors too large for one workgroup to rotate quickly (configs[2]: 660 x 660): 32 lanes per column
+// pair, the two columns in registers between the dot products and the rotation (<= 1024 rows).  A kernel boundary
+// separates the rounds; k_jac_check closes a sweep (convergence test of jacobi_rsv: the largest cos^2 met < 1e-16).
+// grid (ceil(pairs / 16), nprob), 512 threads.
+__global__ void __launch_bounds__(512) k_jac_round(const SvdDesc* descs, int round) {
+  const SvdDesc D = descs[blockIdx.y];
+  if (D.scal[6] != 0.0) return;                      // converged
+  const int m = D.Rr, n = min(D.r1, D.Rr);
+  const int ne = (n + 1) & ~1;
+  if (round >= ne - 1) return;
+  const int pi = blockIdx.x * 16 + (threadIdx.x >> 5), sub = threadIdx.x & 31;
+  if (pi >= ne / 2) return;
+  int p, q;
+  if (pi == 0) { p = ne - 1; q = round; }
+  else {
+    p = round + pi; p -= (p >= ne - 1) ? (ne - 1) : 0;
+    q = round + (ne - 1) - pi; q -= (q >= ne - 1) ? (ne - 1) : 0;
+  }
+  if (p > q) { const int t_ = p; p = q; q = t_; }
+  if (q >= n) return;                                // the dummy player of an odd tournament
+  const int ldJ = m | 1;
+  gdbl* ap = (gdbl*)D.JA + (int64_t)ldJ * p;
+  gdbl* aq = (gdbl*)D.JA + (int64_t)ldJ * q;
+  double x[32], y[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    const int r = sub + 32 * i;
+    const bool ok = r < m;
+    const int rc = ok ? r : sub;
+    const double xv = ap[rc], yv = aq[rc];
+    x[i] = ok ? xv : 0.0; y[i] = ok ? yv : 0.0;
+  }
+  double al = 0, be = 0, ga = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) { al += x[i] * x[i]; be += y[i] * y[i]; ga += x[i] * y[i]; }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { al += __shfl_xor(al, o, 32); be += __shfl_xor(be, o, 32); ga += __shfl_xor(ga, o, 32); }
+  const double nul = 1e-28 * D.scal[3], tol = 1e-15;
+  if (!(ga * ga > (tol * tol) * (al * be) && al > nul && be > nul)) return;
+  double c, s;
+  jac_cs(al, be, ga, c, s);
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    const int r = sub + 32 * i;
+    if (r < m) { ap[r] = c * x[i] - s * y[i]; aq[r] = s * x[i] + c * y[i]; }
+  }
+  if (sub == 0) atomicMax((unsigned long long*)(D.scal + 4), (unsigned long long)__double_as_longlong(ga * ga / (al * be)));
+}
+__global__ void k_jac_check(const SvdDesc* descs, int nprob) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nprob) return;
+  const SvdDesc D = descs[i];
+  if (D.scal[6] != 0.0) return;
+  D.scal[5] += 1.0;
+  if (D.scal[4] < 1e-16) D.scal[6] = 1.0;
+  D.scal[4] = 0.0;
+}
+
+// *pending = number of problems whose Jacobi has not converged yet (the host polls it every few sweeps); one workgroup
+__global__ void k_jac_pending(const SvdDesc* descs, int nprob, int* pending) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < nprob; i += blockDim.x) mine += descs[i].scal[6] == 0.0 ? 1 : 0;
+  if (mine) atomicAdd(&cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) *pending = cnt;
 }
 
 // last core of the truncating sweep: [kc, 1, s] = N_t[(k,s), 0]; grid (nprob)

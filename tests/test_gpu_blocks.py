@@ -144,3 +144,25 @@ def test_qr_batched_many_problems_fused_update():
             sgn = np.sign(np.diag(Rn)) * np.sign(np.diag(R[p]))
             sgn[sgn == 0] = 1
             assert np.abs(R[p] * sgn[:, None] - Rn).max() < 1e-11 * np.abs(Rn).max(), (r, c, p)
+
+
+@pytest.mark.parametrize("m,n", [(4, 4), (9, 7), (40, 40), (80, 33), (360, 360), (660, 500)])
+def test_jacobi_grid_singular_values(m, n):
+    """The multi-launch one-sided Jacobi of the batched truncating sweep (k_jac_round / k_jac_check; configs[2]'s
+    660-column factors) on lower-triangular matrices with singular values spread over 22 decades, as the engine meets
+    them: converges in a few sweeps to LAPACK's singular values."""
+    rng = np.random.default_rng(31)
+    U, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.logspace(0, -22, n)
+    Mx = (U[:, :n] * s) @ V.T
+    # JA = R2^T with R2 the triangular / trapezoidal factor of M^T (M: m x n), as k_svd_trunc builds it
+    A = np.asfortranarray(np.linalg.qr(Mx.T, mode="r").T.copy())
+    sig = np.zeros(n)
+    sw = C.c_int32(0)
+    rc = mpbp_amd._lib.lib().mpbp_selftest_jacobi_grid(0, A.shape[0], n, _dp(A), _dp(sig), 30, C.byref(sw))
+    assert rc == 0
+    assert 0 < sw.value <= 14, sw.value
+    ref = np.linalg.svd(A, compute_uv=False)
+    got = np.sort(sig)[::-1]
+    assert np.abs(got - ref).max() < 1e-13 * ref[0]

@@ -16,7 +16,7 @@ allnodes = np.arange(N, dtype=np.int32)
 if os.environ.get("CFG3_RANDOM"):
     rng = np.random.default_rng(5)
     ptr, ine, oute = bp.g.nbr_arrays()
-    tgt = [int(i) for i in np.nonzero((deg >= 2) & (deg <= 5))[0][:48]]
+    tgt = [int(i) for i in np.nonzero((deg >= 2) & (deg <= 5))[0][:48]] + ([int(np.argmax(deg))] if os.environ.get('CFG3_HUB') else [])
     msgs = [None] * bp.g.ne()
     for i in tgt:
         for p_ in range(ptr[i], ptr[i + 1]):
@@ -26,7 +26,7 @@ else:
     for s in range(2):
         t0 = time.time(); M.onebpiter(bp, allnodes, M.TruncBond(Mb)); print("full sweep", s, time.time() - t0, "maxbond", bp.bonds().max(), flush=True)
 hub = int(np.argmax(deg))
-subs = [] if os.environ.get('CFG3_ONLY_FULL') else [[int(np.nonzero(deg == 4)[0][0])], [int(i) for i in np.nonzero((deg >= 2) & (deg <= 5))[0][:48]]][:(0 if os.environ.get('CFG3_ONLY_FULL') else 2)]
+subs = [] if (os.environ.get('CFG3_ONLY_FULL') or os.environ.get('CFG3_HUB')) else [[int(np.nonzero(deg == 4)[0][0])], [int(i) for i in np.nonzero((deg >= 2) & (deg <= 5))[0][:48]]][:(0 if os.environ.get('CFG3_ONLY_FULL') else 2)]
 if len(sys.argv) > 2: subs.append([hub])
 for sub in subs:
     t0 = time.time(); M.onebpiter(bp, np.array(sub, dtype=np.int32), M.TruncBond(Mb)); st = bp.last_stats
