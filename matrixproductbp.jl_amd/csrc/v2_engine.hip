@@ -91,9 +91,17 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       // few large problems: (16 tiles x row chunk) workgroups with the panels shared through LDS, two launches
       const bool coop = !fused && npmax == 4 && ntile4 > 0 && !getenv("MPBP_DEBUG_NO_COOP_TRAIL");
       if (coop) {
-        const dim3 gc((ntile4 + 15) / 16, nchunk, P);
-        hipLaunchKernelGGL(v2::k_trailW_coop, gc, dim3(512), 0, st, d_probs, lay, jb);
-        hipLaunchKernelGGL(v2::k_trailU_coop, gc, dim3(512), 0, st, d_probs, lay, jb);
+        static const int coop_nt = [] { const char* e = getenv("MPBP_COOP_NT"); return e ? atoi(e) : 0; }();
+        const bool nt1 = coop_nt != 2;   // one tile per wave measured 8-20 % faster at every size tried (two workgroups per CU)
+        if (nt1) {
+          const dim3 gc((ntile4 + 7) / 8, nchunk, P);
+          hipLaunchKernelGGL(v2::k_trailW_coop<1>, gc, dim3(512), 0, st, d_probs, lay, jb);
+          hipLaunchKernelGGL(v2::k_trailU_coop<1>, gc, dim3(512), 0, st, d_probs, lay, jb);
+        } else {
+          const dim3 gc((ntile4 + 15) / 16, nchunk, P);
+          hipLaunchKernelGGL(v2::k_trailW_coop<2>, gc, dim3(512), 0, st, d_probs, lay, jb);
+          hipLaunchKernelGGL(v2::k_trailU_coop<2>, gc, dim3(512), 0, st, d_probs, lay, jb);
+        }
       }
       const int only_short = (fused || coop) ? 1 : 0;
       if ((!fused && !coop) || kmax_min - jb < 64) {

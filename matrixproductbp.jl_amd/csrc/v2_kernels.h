@@ -732,7 +732,8 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
 // the four panels is loaded once by the workgroup into a double-buffered LDS tile (column stride 34 rows: conflict free
 // for both fragment shapes; heads in unit-lower-trapezoidal form), C goes HBM -> registers (one stage prefetched),
 // stage barriers order LDS only.  Problems with four full panels in the block; the others take k_trailW / k_trailU<NP>.
-// grid (ceil(ntile / 16), nchunk, nprob), 512 threads.
+// NT = tiles per wave: 2 (16 tiles per workgroup, one workgroup per CU) or 1 (8 tiles, two workgroups per CU: more
+// workgroups for small grids, more waves to hide latency).  grid (ceil(ntile / (8 NT)), nchunk, nprob), 512 threads.
 // ------------------------------------------------------------------------------------------------------------------
 struct CoopStage {
   const gdbl* vsrc; int sc, sr, spanel, scol;
@@ -757,12 +758,13 @@ struct CoopStage {
   }
 };
 
-__global__ void __launch_bounds__(512) k_trailW_coop(const QrProb* probs, AuxLay lay, int jb) {
+template <int NT>
+__global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailW_coop(const QrProb* probs, AuxLay lay, int jb) {
   const QrProb P = probs[blockIdx.z];
   if (P.kmax - jb < 64) return;
   const int c0 = jb + 64;
   const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
-  if (blockIdx.x * 16 >= ntile) return;
+  if (blockIdx.x * 8 * NT >= ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
   const int s0 = max(chunk * CH, jb) >> 5, s1 = min((chunk + 1) * CH, rows32) >> 5;     // stages of this chunk
@@ -773,27 +775,29 @@ __global__ void __launch_bounds__(512) k_trailW_coop(const QrProb* probs, AuxLay
   const long ld = P.ld;
   __shared__ double vs_[2 * QR_VS_STAGE];
   ldbl* Vs = (ldbl*)vs_;
-  const int tile = blockIdx.x * 16 + 2 * wave;
-  const int nt = max(0, min(2, ntile - tile));
+  const int tile = blockIdx.x * 8 * NT + NT * wave;
+  const int nt = max(0, min(NT, ntile - tile));
   const int cq0 = c0 + 16 * ((nt >= 1) ? tile : 0), cq1 = (nt >= 2) ? cq0 + 16 : cq0;
-  d4 w0[4][2];
+  d4 w0[4][NT];
 #pragma unroll
-  for (int p = 0; p < 4; p++) { w0[p][0] = d4{0, 0, 0, 0}; w0[p][1] = d4{0, 0, 0, 0}; }
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < NT; q++) w0[p][q] = d4{0, 0, 0, 0};
   if (s0 < s1) {
     CoopStage st; st.init(Y, ld, jb);
     const gdbl* c0p = Y + (long)(cq0 + l15) * ld + 4 * g;
     const gdbl* c1p = Y + (long)(cq1 + l15) * ld + 4 * g;
     d4 vreg = st.load(s0, s1 - 1);
     st.store(Vs, s0, jb, vreg);
-    d4 cc[2][2];
+    d4 cc[NT][2];
     cc[0][0] = *reinterpret_cast<const gd4*>(c0p + 32 * s0); cc[0][1] = *reinterpret_cast<const gd4*>(c0p + 32 * s0 + 16);
-    cc[1][0] = *reinterpret_cast<const gd4*>(c1p + 32 * s0); cc[1][1] = *reinterpret_cast<const gd4*>(c1p + 32 * s0 + 16);
+    if (NT > 1) { cc[NT - 1][0] = *reinterpret_cast<const gd4*>(c1p + 32 * s0); cc[NT - 1][1] = *reinterpret_cast<const gd4*>(c1p + 32 * s0 + 16); }
     for (int s = s0; s < s1; s++) {
       vreg = st.load(s + 1, s1 - 1);
       const int sn = min(s + 1, s1 - 1);
-      d4 cn[2][2];
+      d4 cn[NT][2];
       cn[0][0] = *reinterpret_cast<const gd4*>(c0p + 32 * sn); cn[0][1] = *reinterpret_cast<const gd4*>(c0p + 32 * sn + 16);
-      cn[1][0] = *reinterpret_cast<const gd4*>(c1p + 32 * sn); cn[1][1] = *reinterpret_cast<const gd4*>(c1p + 32 * sn + 16);
+      if (NT > 1) { cn[NT - 1][0] = *reinterpret_cast<const gd4*>(c1p + 32 * sn); cn[NT - 1][1] = *reinterpret_cast<const gd4*>(c1p + 32 * sn + 16); }
       lds_barrier();
       const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
       if (nt > 0) {
@@ -804,9 +808,9 @@ __global__ void __launch_bounds__(512) k_trailW_coop(const QrProb* probs, AuxLay
             const ldbl* vp = vb + (16 * p + l15) * QR_VS_LD + 16 * rb + 4 * g;
             const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
             const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
-            if (nt > 1) {
+            if (NT > 1 && nt > 1) {
 #pragma unroll
-              for (int e = 0; e < 4; e++) { w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]); w0[p][1] = mfma(v4[e], cc[1][rb][e], w0[p][1]); }
+              for (int e = 0; e < 4; e++) { w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]); w0[p][NT - 1] = mfma(v4[e], cc[NT - 1][rb][e], w0[p][NT - 1]); }
             } else {
 #pragma unroll
               for (int e = 0; e < 4; e++) w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]);
@@ -815,12 +819,13 @@ __global__ void __launch_bounds__(512) k_trailW_coop(const QrProb* probs, AuxLay
         }
       }
       st.store(Vs, s + 1, jb, vreg);
-      cc[0][0] = cn[0][0]; cc[0][1] = cn[0][1]; cc[1][0] = cn[1][0]; cc[1][1] = cn[1][1];
+#pragma unroll
+      for (int q = 0; q < NT; q++) { cc[q][0] = cn[q][0]; cc[q][1] = cn[q][1]; }
     }
   }
   // partial products of this chunk, in the slot layout k_trailU reads (row sub-chunk 0 of 4)
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
+  for (int q = 0; q < NT; q++) {
     if (q < nt) {
       gdbl* w0o = aux + lay.w0 + ((long)(tile + q) * (lay.nchunk * 4) + chunk * 4) * 1024;
 #pragma unroll
@@ -831,12 +836,13 @@ __global__ void __launch_bounds__(512) k_trailW_coop(const QrProb* probs, AuxLay
   }
 }
 
-__global__ void __launch_bounds__(512) k_trailU_coop(const QrProb* probs, AuxLay lay, int jb) {
+template <int NT>
+__global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailU_coop(const QrProb* probs, AuxLay lay, int jb) {
   const QrProb P = probs[blockIdx.z];
   if (P.kmax - jb < 64) return;
   const int c0 = jb + 64;
   const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
-  if (blockIdx.x * 16 >= ntile) return;
+  if (blockIdx.x * 8 * NT >= ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
   const int s0 = max(chunk * CH, jb) >> 5, s1 = min((chunk + 1) * CH, rows32) >> 5;
@@ -852,8 +858,8 @@ __global__ void __launch_bounds__(512) k_trailU_coop(const QrProb* probs, AuxLay
   ldbl* Vs = Sq + 6 * 256;
   for (int i = tid; i < 4 * 256; i += 512) Tq[i] = aux[lay.T + i];
   for (int i = tid; i < 6 * 256; i += 512) Sq[i] = aux[lay.S + i];
-  const int tile = blockIdx.x * 16 + 2 * wave;
-  const int nt = max(0, min(2, ntile - tile));
+  const int tile = blockIdx.x * 8 * NT + NT * wave;
+  const int nt = max(0, min(NT, ntile - tile));
   const int tq0 = (nt >= 1) ? tile : 0, tq1 = (nt >= 2) ? tile + 1 : tq0;
   const int cq0 = c0 + 16 * tq0, cq1 = c0 + 16 * tq1;
   CoopStage st; st.init(Y, ld, jb);
@@ -862,9 +868,9 @@ __global__ void __launch_bounds__(512) k_trailU_coop(const QrProb* probs, AuxLay
   st.store(Vs, s0, jb, vreg);
   // W of this wave's tiles: partial products of every chunk in a fixed order, then the recurrence
   const int cfirst = jb / CH, clast = (rows32 - 1) / CH;
-  d4 w[4][2];
+  d4 w[4][NT];
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
+  for (int q = 0; q < NT; q++) {
     const int tl = q ? tq1 : tq0;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -890,27 +896,27 @@ __global__ void __launch_bounds__(512) k_trailU_coop(const QrProb* probs, AuxLay
   }
   gdbl* cp0 = Y + (long)(cq0 + g) * ld + 2 * l15;
   gdbl* cp1 = Y + (long)(cq1 + g) * ld + 2 * l15;
-  d2 cc[2][4];
+  d2 cc[NT][4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     cc[0][r] = *reinterpret_cast<const gd2*>(cp0 + (long)(4 * r) * ld + 32 * s0);
-    cc[1][r] = *reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld + 32 * s0);
+    if (NT > 1) cc[NT - 1][r] = *reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld + 32 * s0);
   }
   for (int s = s0; s < s1; s++) {
     vreg = st.load(s + 1, s1 - 1);
     const int sn = min(s + 1, s1 - 1);
-    d2 cn[2][4];
+    d2 cn[NT][4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       cn[0][r] = *reinterpret_cast<const gd2*>(cp0 + (long)(4 * r) * ld + 32 * sn);
-      cn[1][r] = *reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld + 32 * sn);
+      if (NT > 1) cn[NT - 1][r] = *reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld + 32 * sn);
     }
     lds_barrier();
     const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
     if (nt > 0) {
-      d4 acc[2][2];
+      d4 acc[NT][2];
 #pragma unroll
-      for (int q = 0; q < 2; q++)
+      for (int q = 0; q < NT; q++)
 #pragma unroll
         for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
 #pragma unroll
@@ -918,9 +924,9 @@ __global__ void __launch_bounds__(512) k_trailU_coop(const QrProb* probs, AuxLay
 #pragma unroll
         for (int s2 = 0; s2 < 4; s2++) {
           const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * QR_VS_LD + 2 * l15);
-          if (nt > 1) {
+          if (NT > 1 && nt > 1) {
 #pragma unroll
-            for (int e = 0; e < 2; e++) { acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]); acc[1][e] = mfma(-w[p][1][s2], v[e], acc[1][e]); }
+            for (int e = 0; e < 2; e++) { acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]); acc[NT - 1][e] = mfma(-w[p][NT - 1][s2], v[e], acc[NT - 1][e]); }
           } else {
 #pragma unroll
             for (int e = 0; e < 2; e++) acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]);
@@ -929,12 +935,14 @@ __global__ void __launch_bounds__(512) k_trailU_coop(const QrProb* probs, AuxLay
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         *reinterpret_cast<gd2*>(cp0 + (long)(4 * r) * ld + 32 * s) = d2{acc[0][0][r], acc[0][1][r]};
-        if (nt > 1) *reinterpret_cast<gd2*>(cp1 + (long)(4 * r) * ld + 32 * s) = d2{acc[1][0][r], acc[1][1][r]};
+        if (NT > 1 && nt > 1) *reinterpret_cast<gd2*>(cp1 + (long)(4 * r) * ld + 32 * s) = d2{acc[NT - 1][0][r], acc[NT - 1][1][r]};
       }
     }
     st.store(Vs, s + 1, jb, vreg);
 #pragma unroll
-    for (int r = 0; r < 4; r++) { cc[0][r] = cn[0][r]; cc[1][r] = cn[1][r]; }
+    for (int q = 0; q < NT; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) cc[q][r] = cn[q][r];
   }
 }
 
