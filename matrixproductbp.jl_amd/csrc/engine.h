@@ -166,7 +166,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
     qr_r(Y, ldY, rowsY, Bm, ldsQ, ldsG, pr, &plast, PH_QR1_PANEL, PH_QR1_TRAIL, cfg.force_generic != 0);
     const int kmax = min(rowsY, Bm);
     // scale = max |R| over the upper trapezoid; Lf^T = R / scale  (column loops: no integer division)
-    const int lane_ = tid & 63, wave_ = tid >> 6;
+    const int lane_ = tid & 63, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
     double mx = 0.0;
     for (int m = wave_; m < Bm; m += WG_WAVES) {
       const gdbl* yc = Y + (int64_t)ldY * m;

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(512) k_colstep(const QrProb* probs, AuxLay lay
   const int rows32 = (P.rows + 31) & ~31;
   const int cfirst = jp / CH, clast = (rows32 - 1) / CH;
   if (chunk < cfirst || chunk > clast) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   gdbl* Y = (gdbl*)P.Y;
   gdbl* aux = (gdbl*)P.aux;
   const long ld = P.ld;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(512) k_colsteps_coop(const QrProb* probs, AuxL
   const int cfirst = jp / CH, clast = (rows32 - 1) / CH;
   if (chunk < cfirst || chunk > clast) return;
   const int nwg = clast - cfirst + 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   gdbl* Y = (gdbl*)P.Y;
   gdbl* aux = (gdbl*)P.aux;
   int* bar = (int*)(P.aux + lay.bar);
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(512) k_inblock(const QrProb* probs, AuxLay lay
   const QrProb P = probs[blockIdx.x];
   const int cb0 = jb + 16 * NP;
   if (cb0 >= P.kmax) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   gdbl* Y = (gdbl*)P.Y;
   const gdbl* aux = (const gdbl*)P.aux;
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256, NT == 1 ? 3 : 2) k_trail4f(const QrProb* 
   const int c0 = jb + 64;
   const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
   if (blockIdx.x * 4 * NT >= ntile) return;
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const gdbl* aux = (const gdbl*)P.aux;
   __shared__ double ts_[10 * 256];
   ldbl* T0 = (ldbl*)ts_;
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(512) k_gram(const QrProb* probs, AuxLay lay, i
   const int rows32 = (P.rows + 31) & ~31;
   const int cfirst = jx / CH, clast = (rows32 - 1) / CH;
   if (chunk < cfirst || chunk > clast) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const gdbl* Y = (const gdbl*)P.Y;
   gdbl* aux = (gdbl*)P.aux;
@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay,
   if (jb >= P.kmax) return;
   if (only_short && P.kmax - jb >= 64) return;        // k_trail4f has taken the problems with four panels
   const TrailGeom G = trail_geom(P, jb, NP, inblock != 0);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int rw = 4 / tw;
   const int tile = blockIdx.x * tw + (wave % tw), rsub = wave / tw;
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
   if (only_short && P.kmax - jb >= 64) return;
   const TrailGeom G = trail_geom(P, jb, NP, inblock != 0);
   if (G.ntile == 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   gdbl* Y = (gdbl*)P.Y;
   const gdbl* aux = (const gdbl*)P.aux;
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailW_coop(const QrPr
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
   const int s0 = max(chunk * CH, jb) >> 5, s1 = min((chunk + 1) * CH, rows32) >> 5;     // stages of this chunk
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const gdbl* Y = (const gdbl*)P.Y;
   gdbl* aux = (gdbl*)P.aux;
@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailU_coop(const QrPr
   const int chunk = blockIdx.y;
   const int s0 = max(chunk * CH, jb) >> 5, s1 = min((chunk + 1) * CH, rows32) >> 5;
   if (s0 >= s1) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   gdbl* Y = (gdbl*)P.Y;
   const gdbl* aux = (const gdbl*)P.aux;
@@ -962,7 +962,7 @@ struct GemmDesc {
 __global__ void __launch_bounds__(512) k_gemm(const GemmDesc* descs) {
   const GemmDesc D = descs[blockIdx.y];
   if (D.M <= 0 || D.N <= 0) return;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile0 = blockIdx.x * 8 + wave, tstride = gridDim.x * 8;
   if (blockIdx.x * 8 * 16 >= D.N) return;           // whole workgroup beyond the last tile
   gemm_direct<false, false>(D.M, D.N, D.K, (const gdbl*)D.S, D.sro, D.sco, (const gdbl*)D.X, D.xro, D.xco, (gdbl*)D.O,

@@ -45,7 +45,7 @@ __device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* 
   gemm_direct<false, false>(M, N, K, Sp, sro, sco, Xp, xro, xco, Op, oro, oco, accumulate);
 #else
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   ldbl* As = lds;
   ldbl* Bs = lds + GM_KC * GM_LDA;
@@ -182,7 +182,7 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
   // tile0 / tstride: first 16-column output tile of this wave and the stride to its next one (defaults: the waves of
   // ONE workgroup share the tiles; the grid-level contractions of the batched sweep pass global wave numbers)
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int nks = (K + 3) >> 2;
   const int ntile = (N + 15) >> 4;
@@ -423,7 +423,7 @@ __device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane, int&
 template <int JJ>
 __device__ __forceinline__ void qr_panel_step(double (&P)[QR_RS][QR_NB], const bool (&rv)[QR_RS], gdbl* Y, long ld,
                                               int j0, ldbl* red, ldbl* tau, ldbl* tot, ldbl* rowb) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   (void)tot;
   ldbl* redj = red + WG_WAVES * 16 * (JJ & 1);   // partials and pivot row are double buffered by column parity:
   ldbl* rowj = rowb + 16 * (JJ & 1);             // ONE barrier per column
@@ -552,7 +552,7 @@ __device__ __attribute__((noinline)) void qr_panel_regs(gdbl* Y, long ld, int ro
 template <bool TWO>
 __device__ __forceinline__ void qr_gram(const gdbl* Y, long ld, int rows32, int jrow, int jx, int nbx, int jy,
                                         int nby, int jz, int nbz, ldbl* big) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - jrow) >> 4;
   const gdbl* xcol = Y + (long)(jx + l15) * ld + jrow + 4 * g;
@@ -626,7 +626,7 @@ __device__ __forceinline__ void qr_gram(const gdbl* Y, long ld, int rows32, int 
 template <int NP>
 __device__ __forceinline__ void qr_gramN(const gdbl* Y, long ld, int rows32, int jrow, int jx, const int (&jy)[NP],
                                          ldbl* big) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - jrow) >> 4;
   const gdbl* xcol = Y + (long)(jx + l15) * ld + jrow + 4 * g;
@@ -724,7 +724,7 @@ __device__ __forceinline__ void qr_T_from_gram(const ldbl* big, const ldbl* tau,
 // generic panel factorisation, panel in global memory (any number of rows)
 __device__ __attribute__((noinline)) void qr_panel_global(gdbl* Y, long ld, int rows, int j0, int nb, ldbl* red, ldbl* Ts,
                                        ldbl* tau, ldbl* bc) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int jj = 0; jj < nb; jj++) {
     const int col = j0 + jj;
     gdbl* x = Y + (long)col * ld;
@@ -999,7 +999,7 @@ __device__ __forceinline__ void qr_trail2(gdbl* Y, long ld, int rows32, int j0, 
 // W0 partials -> LDS, every wave then applies W = T^T W0 to its own 32-row stages.
 __device__ __forceinline__ void qr_tile_update_all(gdbl* Y, long ld, int rows32, int j0, int nb, int cb0,
                                                    const ldbl* Ts, ldbl* big) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - j0) >> 4;
   const gdbl* vcol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void qr_tile_update_all(gdbl* Y, long ld, int rows32,
 template <int NT>
 __device__ __forceinline__ void qr_tile_update2_all(gdbl* Y, long ld, int rows32, int j0, int cb0, const ldbl* TsA,
                                                     const ldbl* TsB, const ldbl* Sm, ldbl* big) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - j0) >> 4;
   const gdbl* vacol = Y + (long)(j0 + l15) * ld + j0 + 4 * g;
@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
 // build of this function was observed to return wrong results although its source had not changed.
 __device__ __attribute__((noinline)) void qr_tile_update4_all(gdbl* Y, long ld, int rows32, int j0, int cb0,
                                                     const ldbl* const (&Tq)[4], const ldbl* const (&Sq)[6], ldbl* big) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int nrb = (rows32 - j0) >> 4;
   const gdbl* vcol[4];
@@ -1402,11 +1402,15 @@ __device__ __attribute__((noinline)) void qr_tile_update4_all(gdbl* Y, long ld, 
 constexpr int QR_VS_LD = 34;
 constexpr int QR_VS_STAGE = 64 * QR_VS_LD;
 typedef __attribute__((address_space(3))) d2 ld2;
-__device__ __attribute__((noinline)) void qr_trail4_coop(gdbl* Y, long ld, int rows32, int j0, int cstart, int ntl,
-                                                         const ldbl* const (&Tq)[4], const ldbl* const (&Sq)[6], ldbl* Vs) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One pass of qr_trail4_coop for a wave that owns NTL (0, 1 or 2: compile time, so that the stage loops are straight-line
+// code the scheduler can pipeline - with a run-time tile count every group of MFMAs sat in its own basic block behind an
+// s_waitcnt lgkmcnt(0)) tiles at columns cq0, cq1.  Every wave executes the same barriers whatever its NTL.
+template <int NTL>
+__device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, int nst, int cq0, int cq1,
+                                                    const ldbl* const (&Tq)[4], const ldbl* const (&Sq)[6], ldbl* Vs) {
+  constexpr int NR = NTL > 0 ? NTL : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int g = lane >> 4, l15 = lane & 15;
-  const int nst = (rows32 - j0) >> 5;                     // 32-row stages (j0 is a multiple of 64)
   // staging map: thread -> (column sc of the 64, rows 4*sr .. 4*sr+3 of the stage)
   const int sc = tid >> 3, sr = tid & 7;
   const gdbl* vsrc = Y + (long)(j0 + sc) * ld + j0 + 4 * sr;
@@ -1427,71 +1431,68 @@ __device__ __attribute__((noinline)) void qr_trail4_coop(gdbl* Y, long ld, int r
     *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
     *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
   };
-  // this wave's tiles: contiguous run (as wave_tiles)
-  const int tbase = ntl / WG_WAVES, trem = ntl % WG_WAVES;
-  const int tcnt = tbase + (wave < trem ? 1 : 0);
-  const int tstart = wave * tbase + min(wave, trem);
-  const int npass = (tbase + (trem ? 1 : 0) + 1) >> 1;
-  for (int pass = 0; pass < npass; pass++) {
-    const int t0 = 2 * pass;
-    const int nt = max(0, min(2, tcnt - t0));               // tiles of this wave in this pass (wave-uniform)
-    const int cb0 = cstart + 16 * (tstart + t0);
-    // clamp the column pointers of absent tiles to a valid tile (loaded, never stored)
-    const int cq0 = (nt >= 1) ? cb0 : cstart, cq1 = (nt >= 2) ? cb0 + 16 : cq0;
-    // ------------------------------------------------------------ phase A: W0_p = V_p^T C
-    d4 w0[4][2];
+  const int cq[2] = {cq0, cq1};
+  // ------------------------------------------------------------ phase A: W0_p = V_p^T C
+  d4 w0[4][NR];
 #pragma unroll
-    for (int p = 0; p < 4; p++) { w0[p][0] = d4{0, 0, 0, 0}; w0[p][1] = d4{0, 0, 0, 0}; }
-    {
-      const gdbl* c0p = Y + (long)(cq0 + l15) * ld + j0 + 4 * g;
-      const gdbl* c1p = Y + (long)(cq1 + l15) * ld + j0 + 4 * g;
-      d4 vreg = stage_load(0);
-      __syncthreads();                                      // the previous users of Vs are done
-      stage_store(0, vreg);
-      d4 cc[2][2];                                          // [tile][row block of the stage], one stage ahead
-      cc[0][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c0p));
-      cc[0][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c0p + 16));
-      cc[1][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c1p));
-      cc[1][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c1p + 16));
-      for (int s = 0; s < nst; s++) {
-        vreg = stage_load(s + 1);
-        const int sn = min(s + 1, nst - 1);
-        d4 cn[2][2];
-        cn[0][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c0p + 32 * sn));
-        cn[0][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c0p + 32 * sn + 16));
-        cn[1][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c1p + 32 * sn));
-        cn[1][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(c1p + 32 * sn + 16));
-        lds_barrier();                                      // stage s is in Vs[s & 1]; the prefetches stay in flight
-        const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
-        if (nt > 0) {
+  for (int p = 0; p < 4; p++)
 #pragma unroll
-          for (int rb = 0; rb < 2; rb++) {
+    for (int q = 0; q < NR; q++) w0[p][q] = d4{0, 0, 0, 0};
+  {
+    const gdbl* cp[NR];
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-              const ldbl* vp = vb + (16 * p + l15) * QR_VS_LD + 16 * rb + 4 * g;
-              const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
-              const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
-              if (nt > 1) {
+    for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + l15) * ld + j0 + 4 * g;
+    d4 vreg = stage_load(0);
+    __syncthreads();                                      // the previous users of Vs are done
+    stage_store(0, vreg);
+    d4 cc[NR][2];                                         // [tile][row block of the stage], one stage ahead
+    if (NTL > 0) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                  w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]);
-                  w0[p][1] = mfma(v4[e], cc[1][rb][e], w0[p][1]);
-                }
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) w0[p][0] = mfma(v4[e], cc[0][rb][e], w0[p][0]);
-              }
-            }
-          }
-        }
-        stage_store(s + 1, vreg);                           // into the other buffer: nobody reads it before the next barrier
-        cc[0][0] = cn[0][0]; cc[0][1] = cn[0][1]; cc[1][0] = cn[1][0]; cc[1][1] = cn[1][1];
+      for (int q = 0; q < NR; q++) {
+        cc[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q]));
+        cc[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 16));
       }
     }
-    // ------------------------------------------------------------ phase B: the W recurrence (registers)
-    d4 w[4][2];
+    for (int s = 0; s < nst; s++) {
+      vreg = stage_load(s + 1);
+      const int sn = min(s + 1, nst - 1);
+      d4 cn[NR][2];
+      if (NTL > 0) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < NR; q++) {
+          cn[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn));
+          cn[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn + 16));
+        }
+      }
+      lds_barrier();                                      // stage s is in Vs[s & 1]; the prefetches stay in flight
+      if (NTL > 0) {
+        const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            const ldbl* vp = vb + (16 * p + l15) * QR_VS_LD + 16 * rb + 4 * g;
+            const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
+            const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+              for (int q = 0; q < NR; q++) w0[p][q] = mfma(v4[e], cc[q][rb][e], w0[p][q]);
+          }
+        }
+      }
+      stage_store(s + 1, vreg);                           // into the other buffer: nobody reads it before the next barrier
+      if (NTL > 0) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) { cc[q][0] = cn[q][0]; cc[q][1] = cn[q][1]; }
+      }
+    }
+  }
+  // ------------------------------------------------------------ phase B: the W recurrence (registers)
+  d4 w[4][NR];
+  if (NTL > 0) {
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
 #pragma unroll
       for (int p = 0; p < 4; p++) {
         d4 t = w0[p][q];
@@ -1507,63 +1508,84 @@ __device__ __attribute__((noinline)) void qr_trail4_coop(gdbl* Y, long ld, int r
         w[p][q] = o;
       }
     }
-    // ------------------------------------------------------------ phase C: C^T -= sum_p W_p^T V_p^T
-    {
-      d4 vreg = stage_load(0);
-      __syncthreads();                                      // every wave has left phase A's last stage
-      stage_store(0, vreg);
-      gdbl* cp0 = Y + (long)(cq0 + g) * ld + j0 + 2 * l15;
-      gdbl* cp1 = Y + (long)(cq1 + g) * ld + j0 + 2 * l15;
-      d2 cc[2][4];
+  }
+  // ------------------------------------------------------------ phase C: C^T -= sum_p W_p^T V_p^T
+  {
+    d4 vreg = stage_load(0);
+    __syncthreads();                                      // every wave has left phase A's last stage
+    stage_store(0, vreg);
+    gdbl* cp[NR];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        cc[0][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp0 + (long)(4 * r) * ld));
-        cc[1][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld));
+    for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + g) * ld + j0 + 2 * l15;
+    d2 cc[NR][4];
+    if (NTL > 0) {
+#pragma unroll
+      for (int q = 0; q < NR; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cc[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld));
+    }
+    for (int s = 0; s < nst; s++) {
+      vreg = stage_load(s + 1);
+      const int sn = min(s + 1, nst - 1);
+      d2 cn[NR][4];
+      if (NTL > 0) {
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            cn[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld + 32 * sn));
       }
-      for (int s = 0; s < nst; s++) {
-        vreg = stage_load(s + 1);
-        const int sn = min(s + 1, nst - 1);
-        d2 cn[2][4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          cn[0][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp0 + (long)(4 * r) * ld + 32 * sn));
-          cn[1][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp1 + (long)(4 * r) * ld + 32 * sn));
-        }
-        lds_barrier();
+      lds_barrier();
+      if (NTL > 0) {
         const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
-        if (nt > 0) {
-          d4 acc[2][2];                                     // [tile][e]
+        d4 acc[NR][2];                                    // [tile][e]
 #pragma unroll
-          for (int q = 0; q < 2; q++)
+        for (int q = 0; q < NR; q++)
 #pragma unroll
-            for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
+          for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
 #pragma unroll
-          for (int p = 0; p < 4; p++)
+        for (int p = 0; p < 4; p++)
 #pragma unroll
-            for (int s2 = 0; s2 < 4; s2++) {
-              const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * QR_VS_LD + 2 * l15);
-              if (nt > 1) {
+          for (int s2 = 0; s2 < 4; s2++) {
+            const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * QR_VS_LD + 2 * l15);
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                  acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]);
-                  acc[1][e] = mfma(-w[p][1][s2], v[e], acc[1][e]);
-                }
-              } else {
+            for (int e = 0; e < 2; e++)
 #pragma unroll
-                for (int e = 0; e < 2; e++) acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]);
-              }
-            }
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            __builtin_nontemporal_store(d2{acc[0][0][r], acc[0][1][r]}, reinterpret_cast<gd2*>(cp0 + (long)(4 * r) * ld + 32 * s));
-            if (nt > 1) __builtin_nontemporal_store(d2{acc[1][0][r], acc[1][1][r]}, reinterpret_cast<gd2*>(cp1 + (long)(4 * r) * ld + 32 * s));
+              for (int q = 0; q < NR; q++) acc[q][e] = mfma(-w[p][q][s2], v[e], acc[q][e]);
           }
-        }
-        stage_store(s + 1, vreg);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { cc[0][r] = cn[0][r]; cc[1][r] = cn[1][r]; }
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            __builtin_nontemporal_store(d2{acc[q][0][r], acc[q][1][r]}, reinterpret_cast<gd2*>(cp[q] + (long)(4 * r) * ld + 32 * s));
+      }
+      stage_store(s + 1, vreg);
+      if (NTL > 0) {
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) cc[q][r] = cn[q][r];
       }
     }
+  }
+}
+
+__device__ __attribute__((noinline)) void qr_trail4_coop(gdbl* Y, long ld, int rows32, int j0, int cstart, int ntl,
+                                                         const ldbl* const (&Tq)[4], const ldbl* const (&Sq)[6], ldbl* Vs) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nst = (rows32 - j0) >> 5;                     // 32-row stages (j0 is a multiple of 64)
+  // this wave's tiles: contiguous run (as wave_tiles)
+  const int tbase = ntl / WG_WAVES, trem = ntl % WG_WAVES;
+  const int tcnt = tbase + (wave < trem ? 1 : 0);
+  const int tstart = wave * tbase + min(wave, trem);
+  const int npass = (tbase + (trem ? 1 : 0) + 1) >> 1;
+  for (int pass = 0; pass < npass; pass++) {
+    const int t0 = 2 * pass;
+    const int nt = __builtin_amdgcn_readfirstlane(max(0, min(2, tcnt - t0)));   // tiles of this wave in this pass
+    const int cb0 = cstart + 16 * (tstart + t0);
+    if (nt == 2) qr_trail4_coop_pass<2>(Y, ld, j0, nst, cb0, cb0 + 16, Tq, Sq, Vs);
+    else if (nt == 1) qr_trail4_coop_pass<1>(Y, ld, j0, nst, cb0, cb0, Tq, Sq, Vs);
+    else qr_trail4_coop_pass<0>(Y, ld, j0, nst, cstart, cstart, Tq, Sq, Vs);
   }
   __syncthreads();
 }
@@ -1571,7 +1593,7 @@ __device__ __attribute__((noinline)) void qr_trail4_coop(gdbl* Y, long ld, int r
 // `big`: >= WG_WAVES*1024 doubles of LDS scratch when QR_QUAD (else WG_WAVES*512); may alias the gemm tile buffers
 __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big, Prof* pr = nullptr,
                      unsigned long long* plast = nullptr, int ph_panel = 0, int ph_trail = 0, bool force_generic = false) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   ldbl* red = lds;                      // [2][WG_WAVES*16]
   ldbl* Ts = lds + 2 * WG_WAVES * 16;   // [16*16] T, column-major Ts[i + 16*j]
@@ -1665,8 +1687,11 @@ __device__ void qr_r(gdbl* Y, long ld, int rows, int cols, ldbl* lds, ldbl* big,
         // few tiles left: one tile at a time, rows shared out to all waves
         for (int tl = 0; tl < ntl4; tl++) qr_tile_update4_all(Y, ld, rows32, j0, j0 + 64 + 16 * tl, Tq, Sq, big);
       } else if (WG_WAVES == 8 && !QR_TRAIL_PER_WAVE) {
-        // reflector panels shared through LDS, all waves in step (see qr_trail4_coop)
-        qr_trail4_coop(Y, ld, rows32, j0, j0 + 64, ntl4, Tq, Sq, big);
+        // reflector panels shared through LDS, all waves in step (see qr_trail4_coop).  A tile count of 4k + 1 would
+        // leave three SIMDs idle for a whole tile: the odd tile is updated row-parallel instead.
+        const int rem = ((ntl4 & 3) == 1 && ntl4 > 4) ? 1 : 0;
+        qr_trail4_coop(Y, ld, rows32, j0, j0 + 64, ntl4 - rem, Tq, Sq, big);
+        if (rem) qr_tile_update4_all(Y, ld, rows32, j0, j0 + 64 + 16 * (ntl4 - 1), Tq, Sq, big);
       } else {
         int tstart, tcnt;
         wave_tiles(j0 + 64, tstart, tcnt);

@@ -1,0 +1,220 @@
+// Stall attribution for the cooperative trailing update (wg::qr_trail4_coop_pass<2>): ONE workgroup, 16 tiles (two per
+// wave), 1600 x (64 + 256) matrix, the pass repeated `reps` times.  Each variant removes one ingredient (results are then
+// wrong on purpose; only the time matters):  bit 0: no C global loads / stores, bit 1: no V global loads, bit 2: no LDS
+// reads, bit 3: no barriers, bit 4: no MFMAs.  Standalone tool, not part of the library.
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I matrixproductbp.jl_amd/csrc -o tools/_trail_probe.bin tools/probes/trail_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "wg_common.h"
+using namespace wgc;
+typedef __attribute__((address_space(3))) d2 ld2;
+constexpr int VS_LD = 34, VS_STAGE = 64 * VS_LD;
+
+template <int FL>
+__device__ __forceinline__ void bar() { if (!(FL & 8)) lds_barrier(); }
+
+template <int FL>
+__device__ __forceinline__ void pass(gdbl* Y, long ld, int j0, int nst, int cq0, int cq1, const ldbl* Tq, ldbl* Vs) {
+  constexpr int NR = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int sc = tid >> 3, sr = tid & 7;
+  const gdbl* vsrc = Y + (long)(j0 + sc) * ld + j0 + 4 * sr;
+  const int spanel = sc >> 4, scol = sc & 15;
+  auto stage_load = [&](int s) -> d4 {
+    if (FL & 2) return d4{1e-3, 2e-3, 3e-3, 4e-3};
+    const int sclamp = min(s, nst - 1);
+    return *reinterpret_cast<const gd4*>(vsrc + 32 * sclamp);
+  };
+  auto stage_store = [&](int s, d4 v) {
+    ldbl* dst = Vs + (s & 1) * VS_STAGE + sc * VS_LD + 4 * sr;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rp = 32 * s + 4 * sr + e - 16 * spanel;
+      double a = v[e];
+      a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
+      v[e] = (rp >= 0) ? a : 0.0;
+    }
+    *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
+    *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
+  };
+  const int cq[2] = {cq0, cq1};
+  d4 w0[4][NR];
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < NR; q++) w0[p][q] = d4{0, 0, 0, 0};
+  {
+    const gdbl* cp[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + l15) * ld + j0 + 4 * g;
+    d4 vreg = stage_load(0);
+    __syncthreads();
+    stage_store(0, vreg);
+    d4 cc[NR][2];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      if (FL & 1) { cc[q][0] = d4{1, 2, 3, 4}; cc[q][1] = d4{4, 3, 2, 1}; }
+      else {
+        cc[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q]));
+        cc[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 16));
+      }
+    }
+    for (int s = 0; s < nst; s++) {
+      vreg = stage_load(s + 1);
+      const int sn = min(s + 1, nst - 1);
+      d4 cn[NR][2];
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        if (FL & 1) { cn[q][0] = cc[q][1]; cn[q][1] = cc[q][0]; }
+        else {
+          cn[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn));
+          cn[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn + 16));
+        }
+      }
+      bar<FL>();
+      const ldbl* vb = Vs + (s & 1) * VS_STAGE;
+#pragma unroll
+      for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const ldbl* vp = vb + (16 * p + l15) * VS_LD + 16 * rb + 4 * g;
+          d2 va, vbb;
+          if (FL & 4) { va = d2{cc[0][rb][0] + p, 1.0}; vbb = d2{2.0, cc[1][rb][1]}; }
+          else { va = *reinterpret_cast<const ld2*>(vp); vbb = *reinterpret_cast<const ld2*>(vp + 2); }
+          const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int q = 0; q < NR; q++) {
+              if (FL & 16) w0[p][q][e] += v4[e] * cc[q][rb][e];
+              else w0[p][q] = mfma(v4[e], cc[q][rb][e], w0[p][q]);
+            }
+        }
+      }
+      stage_store(s + 1, vreg);
+#pragma unroll
+      for (int q = 0; q < NR; q++) { cc[q][0] = cn[q][0]; cc[q][1] = cn[q][1]; }
+    }
+  }
+  d4 w[4][NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) o = mfma(Tq[(4 * s + g) + 16 * l15], w0[p][q][s], o);
+      w[p][q] = o;
+    }
+  }
+  {
+    d4 vreg = stage_load(0);
+    __syncthreads();
+    stage_store(0, vreg);
+    gdbl* cp[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + g) * ld + j0 + 2 * l15;
+    d2 cc[NR][4];
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (FL & 1) cc[q][r] = d2{1.0 * r, 2.0 * q};
+        else cc[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld));
+      }
+    for (int s = 0; s < nst; s++) {
+      vreg = stage_load(s + 1);
+      const int sn = min(s + 1, nst - 1);
+      d2 cn[NR][4];
+#pragma unroll
+      for (int q = 0; q < NR; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (FL & 1) cn[q][r] = cc[q][3 - r];
+          else cn[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld + 32 * sn));
+        }
+      bar<FL>();
+      const ldbl* vb = Vs + (s & 1) * VS_STAGE;
+      d4 acc[NR][2];
+#pragma unroll
+      for (int q = 0; q < NR; q++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+          d2 v;
+          if (FL & 4) v = d2{acc[0][0][0] * 1e-9 + p, 1.0 + s2};
+          else v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * VS_LD + 2 * l15);
+#pragma unroll
+          for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int q = 0; q < NR; q++) {
+              if (FL & 16) acc[q][e][s2] -= w[p][q][s2] * v[e];
+              else acc[q][e] = mfma(-w[p][q][s2], v[e], acc[q][e]);
+            }
+        }
+      if (FL & 1) {
+        if (acc[0][0][0] == 12345.678 && acc[1][1][2] == 4.25 && acc[0][1][1] == 7.5 && acc[1][0][3] == -1.25) cp[0][s] = acc[0][0][1];
+      } else {
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            __builtin_nontemporal_store(d2{acc[q][0][r], acc[q][1][r]}, reinterpret_cast<gd2*>(cp[q] + (long)(4 * r) * ld + 32 * s));
+      }
+      stage_store(s + 1, vreg);
+#pragma unroll
+      for (int q = 0; q < NR; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cc[q][r] = cn[q][r];
+    }
+  }
+}
+
+template <int FL>
+__global__ void __launch_bounds__(512) k(double* Y, int ld, int rows32, int reps) {
+  __shared__ __attribute__((aligned(16))) double Vs[2 * VS_STAGE];
+  __shared__ double T[256];
+  if (threadIdx.x < 256) T[threadIdx.x] = 0.0;
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  gdbl* Yg = (gdbl*)Y + (long)blockIdx.x * ld * 336;
+  for (int r = 0; r < reps; r++)
+    pass<FL>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
+}
+
+template <int FL>
+void run(double* d, int ld, int rows32, int blocks, const char* what) {
+  const int reps = 20;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(k<FL>, dim3(blocks), dim3(512), 0, 0, d, ld, rows32, 1);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0); hipLaunchKernelGGL(k<FL>, dim3(blocks), dim3(512), 0, 0, d, ld, rows32, reps); (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  const double ideal = (double)(rows32 >> 5) * 4 * 64 * 64 / 2.4e6;     // ms per pass: 4 tile-stages per SIMD, 64 MFMAs of 64 cycles each
+  printf("blocks %3d  %-44s %7.3f ms per pass  (MFMA-bound %.3f ms, %.0f %%)\n", blocks, what, ms / reps, ideal, 100.0 * ideal / (ms / reps));
+}
+
+int main() {
+  const int rows32 = 1600, ld = 1600, cols = 336;
+  double* d; (void)hipMalloc(&d, sizeof(double) * ld * cols * 256);
+  std::vector<double> h((size_t)ld * cols);
+  for (size_t i = 0; i < h.size(); i++) h[i] = (double)((i * 2654435761u) % 2001) / 1000.0 - 1.0;
+  for (int b = 0; b < 256; b++) (void)hipMemcpy(d + (size_t)b * ld * cols, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+  for (int blocks : {1, 256}) {
+    run<0>(d, ld, rows32, blocks, "as shipped");
+    run<1>(d, ld, rows32, blocks, "no C loads/stores");
+    run<2>(d, ld, rows32, blocks, "no V global loads");
+    run<3>(d, ld, rows32, blocks, "no global traffic at all");
+    run<4>(d, ld, rows32, blocks, "no LDS reads");
+    run<8>(d, ld, rows32, blocks, "no barriers");
+    run<7>(d, ld, rows32, blocks, "no global, no LDS reads");
+    run<15>(d, ld, rows32, blocks, "no global, no LDS reads, no barriers");
+    run<16>(d, ld, rows32, blocks, "no MFMA (scalar stand-in)");
+  }
+  return 0;
+}
