@@ -175,6 +175,181 @@ __device__ __forceinline__ void pass(gdbl* Y, long ld, int j0, int nst, int cq0,
   }
 }
 
+
+// Variant with a three-deep register ring: the C fragments and the V stage are requested TWO stages ahead.
+template <int FL, bool DEEPC>
+__device__ __forceinline__ void pass_deep(gdbl* Y, long ld, int j0, int nst, int cq0, int cq1, const ldbl* Tq, ldbl* Vs) {
+  constexpr int NR = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int sc = tid >> 3, sr = tid & 7;
+  const gdbl* vsrc = Y + (long)(j0 + sc) * ld + j0 + 4 * sr;
+  const int spanel = sc >> 4, scol = sc & 15;
+  auto stage_load = [&](int s) -> d4 {
+    const int sclamp = min(s, nst - 1);
+    return *reinterpret_cast<const gd4*>(vsrc + 32 * sclamp);
+  };
+  auto stage_store = [&](int s, d4 v) {
+    ldbl* dst = Vs + (s & 1) * VS_STAGE + sc * VS_LD + 4 * sr;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rp = 32 * s + 4 * sr + e - 16 * spanel;
+      double a = v[e];
+      a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
+      v[e] = (rp >= 0) ? a : 0.0;
+    }
+    *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
+    *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
+  };
+  const int cq[2] = {cq0, cq1};
+  d4 w0[4][NR];
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < NR; q++) w0[p][q] = d4{0, 0, 0, 0};
+  {
+    const gdbl* cp[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + l15) * ld + j0 + 4 * g;
+    d4 vr[3];
+    d4 c[3][NR][2];
+    auto loadc = [&](d4 (&dst)[NR][2], int s) {
+      const int sn = min(s, nst - 1);
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        dst[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn));
+        dst[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn + 16));
+      }
+    };
+    auto body = [&](int s, d4 (&cur)[NR][2], d4 (&nx2)[NR][2], d4& vnext, d4& vnx2) {
+      vnx2 = stage_load(s + 2);
+      loadc(nx2, s + 2);
+      lds_barrier();
+      const ldbl* vb = Vs + (s & 1) * VS_STAGE;
+#pragma unroll
+      for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const ldbl* vp = vb + (16 * p + l15) * VS_LD + 16 * rb + 4 * g;
+          const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
+          const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int q = 0; q < NR; q++) w0[p][q] = mfma(v4[e], cur[q][rb][e], w0[p][q]);
+        }
+      }
+      stage_store(s + 1, vnext);
+    };
+    vr[0] = stage_load(0); vr[1] = stage_load(1);
+    loadc(c[0], 0); loadc(c[1], 1);
+    __syncthreads();
+    stage_store(0, vr[0]);
+    for (int s = 0; s < nst; s += 3) {
+      body(s, c[0], c[2], vr[1], vr[2]);
+      if (s + 1 < nst) body(s + 1, c[1], c[0], vr[2], vr[0]);
+      if (s + 2 < nst) body(s + 2, c[2], c[1], vr[0], vr[1]);
+    }
+  }
+  d4 w[4][NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) o = mfma(Tq[(4 * s + g) + 16 * l15], w0[p][q][s], o);
+      w[p][q] = o;
+    }
+  }
+  {
+    gdbl* cp[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + g) * ld + j0 + 2 * l15;
+    d4 vr[3];
+    d2 c[3][NR][4];
+    auto loadc = [&](d2 (&dst)[NR][4], int s) {
+      const int sn = min(s, nst - 1);
+#pragma unroll
+      for (int q = 0; q < NR; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          dst[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld + 32 * sn));
+    };
+    auto body = [&](int s, d2 (&cur)[NR][4], d2 (&nx2)[NR][4], d4& vnext, d4& vnx2) {
+      vnx2 = stage_load(s + 2);
+      loadc(nx2, s + 2);
+      lds_barrier();
+      const ldbl* vb = Vs + (s & 1) * VS_STAGE;
+      d4 acc[NR][2];
+#pragma unroll
+      for (int q = 0; q < NR; q++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) acc[q][e] = d4{cur[q][0][e], cur[q][1][e], cur[q][2][e], cur[q][3][e]};
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+          const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * VS_LD + 2 * l15);
+#pragma unroll
+          for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int q = 0; q < NR; q++) acc[q][e] = mfma(-w[p][q][s2], v[e], acc[q][e]);
+        }
+#pragma unroll
+      for (int q = 0; q < NR; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          __builtin_nontemporal_store(d2{acc[q][0][r], acc[q][1][r]}, reinterpret_cast<gd2*>(cp[q] + (long)(4 * r) * ld + 32 * s));
+      stage_store(s + 1, vnext);
+    };
+    vr[0] = stage_load(0); vr[1] = stage_load(1);
+    loadc(c[0], 0); if (DEEPC) loadc(c[1], 1);
+    __syncthreads();
+    stage_store(0, vr[0]);
+    if (DEEPC) {
+      for (int s = 0; s < nst; s += 3) {
+        body(s, c[0], c[2], vr[1], vr[2]);
+        if (s + 1 < nst) body(s + 1, c[1], c[0], vr[2], vr[0]);
+        if (s + 2 < nst) body(s + 2, c[2], c[1], vr[0], vr[1]);
+      }
+    } else {
+      // one stage ahead, unrolled by two so that no register copies (and no wait for them) close a stage
+      auto body1 = [&](int s, d2 (&cur)[NR][4], d2 (&nx)[NR][4], d4& vcur, d4& vnx) {
+        vnx = stage_load(s + 2);
+        loadc(nx, s + 1);
+        lds_barrier();
+        const ldbl* vb = Vs + (s & 1) * VS_STAGE;
+        d4 acc[NR][2];
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+          for (int e = 0; e < 2; e++) acc[q][e] = d4{cur[q][0][e], cur[q][1][e], cur[q][2][e], cur[q][3][e]};
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++) {
+            const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * VS_LD + 2 * l15);
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+#pragma unroll
+              for (int q = 0; q < NR; q++) acc[q][e] = mfma(-w[p][q][s2], v[e], acc[q][e]);
+          }
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            __builtin_nontemporal_store(d2{acc[q][0][r], acc[q][1][r]}, reinterpret_cast<gd2*>(cp[q] + (long)(4 * r) * ld + 32 * s));
+        stage_store(s + 1, vcur);
+      };
+      for (int s = 0; s < nst; s += 2) {
+        body1(s, c[0], c[1], vr[1], vr[0]);
+        if (s + 1 < nst) body1(s + 1, c[1], c[0], vr[0], vr[1]);
+      }
+    }
+  }
+}
+
 template <int FL>
 __global__ void __launch_bounds__(512) k(double* Y, int ld, int rows32, int reps) {
   __shared__ __attribute__((aligned(16))) double Vs[2 * VS_STAGE];
@@ -184,7 +359,9 @@ __global__ void __launch_bounds__(512) k(double* Y, int ld, int rows32, int reps
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   gdbl* Yg = (gdbl*)Y + (long)blockIdx.x * ld * 336;
   for (int r = 0; r < reps; r++)
-    pass<FL>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
+    if (FL == 32) pass_deep<FL, true>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
+    else if (FL == 64) pass_deep<FL, false>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
+    else pass<FL>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
 }
 
 template <int FL>
@@ -207,6 +384,8 @@ int main() {
   for (int b = 0; b < 256; b++) (void)hipMemcpy(d + (size_t)b * ld * cols, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
   for (int blocks : {1, 256}) {
     run<0>(d, ld, rows32, blocks, "as shipped");
+    run<32>(d, ld, rows32, blocks, "two stages of prefetch");
+    run<64>(d, ld, rows32, blocks, "two stages ahead in phase A only");
     run<1>(d, ld, rows32, blocks, "no C loads/stores");
     run<2>(d, ld, rows32, blocks, "no V global loads");
     run<3>(d, ld, rows32, blocks, "no global traffic at all");
