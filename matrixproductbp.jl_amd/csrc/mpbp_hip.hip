@@ -427,7 +427,7 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   else { cfg.lds_JA = cfg.lds_JV = -1; }
   // the gemm tiles (which double as the QR's `big` scratch, WG_WAVES*512 doubles) share the same region: within a
   // time step the staged cores / E are dead once Y_t (sweep 1) or N_t (sweep 2) is built, before any gemm / QR
-  const int64_t gemm_d = pl.small ? 512 : std::max<int64_t>(v512::wg::GM_LDS_DOUBLES, 8 * 1024);   // QR quad scratch: 8 waves x 1024
+  const int64_t gemm_d = pl.small ? 512 : std::max<int64_t>(v512::wg::GM_LDS_DOUBLES, v512::wg::QR_BIG_DOUBLES);   // QR quad scratch / reflector staging
   cfg.lds_gemm = (int32_t)base;
   int64_t top = base + std::max(gemm_d, std::max(cores_fit ? coresE : 0, jac_fit ? jac : 0));
   lds_bytes = (size_t)top * 8;
@@ -1183,8 +1183,8 @@ extern "C" int mpbp_selftest_qr(int32_t device, int32_t rows, int32_t cols, cons
   double* dY;
   STCHK(hipMalloc(&dY, sizeof(double) * Y.size()));
   STCHK(hipMemcpy(dY, Y.data(), sizeof(double) * Y.size(), hipMemcpyHostToDevice));
-  STCHK(hipFuncSetAttribute((const void*)st_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (wg::QR_LDS_DOUBLES + WG_WAVES * 1024) * 8));
-  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 1024) * 8, 0, dY, ld, rows, cols, (wg::Prof*)nullptr);
+  STCHK(hipFuncSetAttribute((const void*)st_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (wg::QR_LDS_DOUBLES + wg::QR_BIG_DOUBLES) * 8));
+  hipLaunchKernelGGL(st_qr_kernel, dim3(1), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + wg::QR_BIG_DOUBLES) * 8, 0, dY, ld, rows, cols, (wg::Prof*)nullptr);
   STCHK(hipGetLastError()); STCHK(hipDeviceSynchronize());
   STCHK(hipMemcpy(Y.data(), dY, sizeof(double) * Y.size(), hipMemcpyDeviceToHost));
   const int k = std::min(rows, cols);
@@ -1204,7 +1204,7 @@ extern "C" int mpbp_selftest_qr_bench(int32_t device, int32_t rows, int32_t cols
   double* dY; double* dY0;
   STCHK(hipMalloc(&dY, sizeof(double) * per * nblocks)); STCHK(hipMalloc(&dY0, sizeof(double) * per));
   STCHK(hipMemcpy(dY0, Y.data(), sizeof(double) * per, hipMemcpyHostToDevice));
-  STCHK(hipFuncSetAttribute((const void*)st_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (wg::QR_LDS_DOUBLES + WG_WAVES * 1024) * 8));
+  STCHK(hipFuncSetAttribute((const void*)st_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (wg::QR_LDS_DOUBLES + wg::QR_BIG_DOUBLES) * 8));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float tot = 0.f;
   wg::Prof* dprof = nullptr;                 // MPBP_QR_PROF=1: per-phase split of the factorisation on stderr
@@ -1214,7 +1214,7 @@ extern "C" int mpbp_selftest_qr_bench(int32_t device, int32_t rows, int32_t cols
     for (int b = 0; b < nblocks; b++) STCHK(hipMemcpyAsync(dY + per * b, dY0, sizeof(double) * per, hipMemcpyDeviceToDevice, 0));
     STCHK(hipDeviceSynchronize());
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(st_qr_kernel, dim3(nblocks), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + WG_WAVES * 1024) * 8, 0, dY, ld, rows, cols, dprof);
+    hipLaunchKernelGGL(st_qr_kernel, dim3(nblocks), dim3(WG_THREADS), (wg::QR_LDS_DOUBLES + wg::QR_BIG_DOUBLES) * 8, 0, dY, ld, rows, cols, dprof);
     hipEventRecord(e1, 0);
     STCHK(hipEventSynchronize(e1));
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);

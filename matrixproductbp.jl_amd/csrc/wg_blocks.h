@@ -1396,37 +1396,44 @@ __device__ __attribute__((noinline)) void qr_tile_update4_all(gdbl* Y, long ld, 
 // read by every wave as LDS fragments, instead of each wave streaming its own copy of V through the vector L1 (which
 // made phase C L1-bound: 16 KB of V per wave and stage against 16 KB of C).  Every wave owns up to NT = 2 tiles per pass
 // (contiguous runs, as wave_tiles); C goes straight from HBM to registers and back (nontemporal).
-//   Vs: 2 * QR_VS_STAGE doubles of LDS (double buffer).  Column stride QR_VS_LD = 34 rows: == 4 banks (mod 64) per
+//   Vs: 2 * QR_VM_STAGE doubles of LDS (double buffer; QR_BIG_DOUBLES covers it).  Column stride == 4 banks (mod 64) per
 //   column, so the phase A reads (16 lanes = 16 columns, 32 B each) and the phase C reads (16 lanes = 32 consecutive
 //   rows of one column) are both conflict free.  One barrier per stage.
-constexpr int QR_VS_LD = 34;
+constexpr int QR_VS_LD = 34;                   // 32-row stages (batched kernels of v2_kernels.h)
 constexpr int QR_VS_STAGE = 64 * QR_VS_LD;
+constexpr int QR_BIG_DOUBLES = (WG_WAVES * 1024 > 2 * 64 * 66) ? WG_WAVES * 1024 : 2 * 64 * 66;   // `big` of qr_r
 typedef __attribute__((address_space(3))) d2 ld2;
 // One pass of qr_trail4_coop for a wave that owns NTL (0, 1 or 2: compile time, so that the stage loops are straight-line
 // code the scheduler can pipeline - with a run-time tile count every group of MFMAs sat in its own basic block behind an
 // s_waitcnt lgkmcnt(0)) tiles at columns cq0, cq1.  Every wave executes the same barriers whatever its NTL.
+// The reflector panels are staged 64 rows at a time (QR_VM_*): ONE barrier per 64 rows; C is still fetched 32 rows
+// ahead.  Every barrier makes all eight waves wait for the slowest C fetch: with 256 workgroups streaming, halving their
+// number took the pass from 0.66 to 0.57 ms (tools/probes/trail_probe.hip).
+constexpr int QR_VM_LD = 66;                   // == 4 banks (mod 64) per column, as QR_VS_LD
+constexpr int QR_VM_STAGE = 64 * QR_VM_LD;
 template <int NTL>
 __device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, int nst, int cq0, int cq1,
                                                     const ldbl* const (&Tq)[4], const ldbl* const (&Sq)[6], ldbl* Vs) {
   constexpr int NR = NTL > 0 ? NTL : 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = lane >> 4, l15 = lane & 15;
-  // staging map: thread -> (column sc of the 64, rows 4*sr .. 4*sr+3 of the stage)
+  const int nms = (nst + 1) >> 1;                         // 64-row stages; the second half of the last one may be empty
+  // staging map: thread -> (column sc of the 64, rows 4*sr .. 4*sr+3 of each 32-row half)
   const int sc = tid >> 3, sr = tid & 7;
   const gdbl* vsrc = Y + (long)(j0 + sc) * ld + j0 + 4 * sr;
   const int spanel = sc >> 4, scol = sc & 15;
-  auto stage_load = [&](int s) -> d4 {
-    const int sclamp = min(s, nst - 1);
-    return *reinterpret_cast<const gd4*>(vsrc + 32 * sclamp);
+  auto stage_load = [&](int m, int h) -> d4 {
+    const int s = min(2 * min(m, nms - 1) + h, nst - 1);
+    return *reinterpret_cast<const gd4*>(vsrc + 32 * s);
   };
-  auto stage_store = [&](int s, d4 v) {
-    ldbl* dst = Vs + (s & 1) * QR_VS_STAGE + sc * QR_VS_LD + 4 * sr;
+  auto stage_store = [&](int m, int h, d4 v) {
+    ldbl* dst = Vs + (m & 1) * QR_VM_STAGE + sc * QR_VM_LD + 32 * h + 4 * sr;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const int rp = 32 * s + 4 * sr + e - 16 * spanel;     // row relative to this panel's diagonal block
+      const int rp = 64 * m + 32 * h + 4 * sr + e - 16 * spanel;     // row relative to this panel's diagonal block
       double a = v[e];
       a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
-      v[e] = (rp >= 0) ? a : 0.0;
+      v[e] = (rp >= 0 && 2 * m + h < nst) ? a : 0.0;                 // rows past the matrix: zero reflector rows
     }
     *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
     *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
@@ -1442,10 +1449,12 @@ __device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, in
     const gdbl* cp[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + l15) * ld + j0 + 4 * g;
-    d4 vreg = stage_load(0);
-    __syncthreads();                                      // the previous users of Vs are done
-    stage_store(0, vreg);
-    d4 cc[NR][2];                                         // [tile][row block of the stage], one stage ahead
+    {
+      const d4 v0 = stage_load(0, 0), v1 = stage_load(0, 1);
+      __syncthreads();                                    // the previous users of Vs are done
+      stage_store(0, 0, v0); stage_store(0, 1, v1);
+    }
+    d4 cc[NR][2];                                         // [tile][row block of the 32 rows], 32 rows ahead
     if (NTL > 0) {
 #pragma unroll
       for (int q = 0; q < NR; q++) {
@@ -1453,38 +1462,39 @@ __device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, in
         cc[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 16));
       }
     }
-    for (int s = 0; s < nst; s++) {
-      vreg = stage_load(s + 1);
-      const int sn = min(s + 1, nst - 1);
-      d4 cn[NR][2];
-      if (NTL > 0) {
+    for (int m = 0; m < nms; m++) {
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {
+        const d4 vn = stage_load(m + 1, h);               // half h of the next stage: stored when this half is done
+        const int sn = min(2 * m + h + 1, nst - 1);
+        d4 cn[NR][2];
+        if (NTL > 0) {
 #pragma unroll
-        for (int q = 0; q < NR; q++) {
-          cn[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn));
-          cn[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn + 16));
-        }
-      }
-      lds_barrier();                                      // stage s is in Vs[s & 1]; the prefetches stay in flight
-      if (NTL > 0) {
-        const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
-#pragma unroll
-        for (int rb = 0; rb < 2; rb++) {
-#pragma unroll
-          for (int p = 0; p < 4; p++) {
-            const ldbl* vp = vb + (16 * p + l15) * QR_VS_LD + 16 * rb + 4 * g;
-            const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
-            const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-#pragma unroll
-              for (int q = 0; q < NR; q++) w0[p][q] = mfma(v4[e], cc[q][rb][e], w0[p][q]);
+          for (int q = 0; q < NR; q++) {
+            cn[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn));
+            cn[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn + 16));
           }
         }
-      }
-      stage_store(s + 1, vreg);                           // into the other buffer: nobody reads it before the next barrier
-      if (NTL > 0) {
+        if (h == 0) lds_barrier();                        // stage m is in Vs[m & 1]; the prefetches stay in flight
+        if (NTL > 0) {
+          const ldbl* vb = Vs + (m & 1) * QR_VM_STAGE + 32 * h;
 #pragma unroll
-        for (int q = 0; q < NR; q++) { cc[q][0] = cn[q][0]; cc[q][1] = cn[q][1]; }
+          for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+              const ldbl* vp = vb + (16 * p + l15) * QR_VM_LD + 16 * rb + 4 * g;
+              const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
+              const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
+#pragma unroll
+              for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int q = 0; q < NR; q++) w0[p][q] = mfma(v4[e], cc[q][rb][e], w0[p][q]);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < NR; q++) { cc[q][0] = cn[q][0]; cc[q][1] = cn[q][1]; }
+        }
+        stage_store(m + 1, h, vn);                        // the other buffer: nobody reads it before the next barrier
       }
     }
   }
@@ -1511,9 +1521,11 @@ __device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, in
   }
   // ------------------------------------------------------------ phase C: C^T -= sum_p W_p^T V_p^T
   {
-    d4 vreg = stage_load(0);
-    __syncthreads();                                      // every wave has left phase A's last stage
-    stage_store(0, vreg);
+    {
+      const d4 v0 = stage_load(0, 0), v1 = stage_load(0, 1);
+      __syncthreads();                                    // every wave has left phase A's last stage
+      stage_store(0, 0, v0); stage_store(0, 1, v1);
+    }
     gdbl* cp[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + g) * ld + j0 + 2 * l15;
@@ -1524,47 +1536,51 @@ __device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, in
 #pragma unroll
         for (int r = 0; r < 4; r++) cc[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld));
     }
-    for (int s = 0; s < nst; s++) {
-      vreg = stage_load(s + 1);
-      const int sn = min(s + 1, nst - 1);
-      d2 cn[NR][4];
-      if (NTL > 0) {
+    for (int m = 0; m < nms; m++) {
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {
+        const d4 vn = stage_load(m + 1, h);
+        const int s = 2 * m + h;
+        const int sn = min(s + 1, nst - 1);
+        d2 cn[NR][4];
+        if (NTL > 0) {
 #pragma unroll
-        for (int q = 0; q < NR; q++)
+          for (int q = 0; q < NR; q++)
 #pragma unroll
-          for (int r = 0; r < 4; r++)
-            cn[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld + 32 * sn));
-      }
-      lds_barrier();
-      if (NTL > 0) {
-        const ldbl* vb = Vs + (s & 1) * QR_VS_STAGE;
-        d4 acc[NR][2];                                    // [tile][e]
+            for (int r = 0; r < 4; r++)
+              cn[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld + 32 * sn));
+        }
+        if (h == 0) lds_barrier();
+        if (NTL > 0) {
+          if (s < nst) {
+            const ldbl* vb = Vs + (m & 1) * QR_VM_STAGE + 32 * h;
+            d4 acc[NR][2];                                // [tile][e]
 #pragma unroll
-        for (int q = 0; q < NR; q++)
+            for (int q = 0; q < NR; q++)
 #pragma unroll
-          for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
+              for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
 #pragma unroll
-        for (int p = 0; p < 4; p++)
+            for (int p = 0; p < 4; p++)
 #pragma unroll
-          for (int s2 = 0; s2 < 4; s2++) {
-            const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * QR_VS_LD + 2 * l15);
+              for (int s2 = 0; s2 < 4; s2++) {
+                const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * QR_VM_LD + 2 * l15);
 #pragma unroll
-            for (int e = 0; e < 2; e++)
+                for (int e = 0; e < 2; e++)
 #pragma unroll
-              for (int q = 0; q < NR; q++) acc[q][e] = mfma(-w[p][q][s2], v[e], acc[q][e]);
+                  for (int q = 0; q < NR; q++) acc[q][e] = mfma(-w[p][q][s2], v[e], acc[q][e]);
+              }
+#pragma unroll
+            for (int q = 0; q < NR; q++)
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                __builtin_nontemporal_store(d2{acc[q][0][r], acc[q][1][r]}, reinterpret_cast<gd2*>(cp[q] + (long)(4 * r) * ld + 32 * s));
           }
 #pragma unroll
-        for (int q = 0; q < NR; q++)
+          for (int q = 0; q < NR; q++)
 #pragma unroll
-          for (int r = 0; r < 4; r++)
-            __builtin_nontemporal_store(d2{acc[q][0][r], acc[q][1][r]}, reinterpret_cast<gd2*>(cp[q] + (long)(4 * r) * ld + 32 * s));
-      }
-      stage_store(s + 1, vreg);
-      if (NTL > 0) {
-#pragma unroll
-        for (int q = 0; q < NR; q++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) cc[q][r] = cn[q][r];
+            for (int r = 0; r < 4; r++) cc[q][r] = cn[q][r];
+        }
+        stage_store(m + 1, h, vn);
       }
     }
   }

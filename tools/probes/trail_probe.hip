@@ -350,16 +350,164 @@ __device__ __forceinline__ void pass_deep(gdbl* Y, long ld, int j0, int nst, int
   }
 }
 
+// Variant with 64-row stages of V in LDS: one barrier per 64 rows instead of per 32 (C still prefetched 32 rows ahead).
+constexpr int VS_LD2 = 66, VS_STAGE2 = 64 * VS_LD2;
+template <int FL>
+__device__ __forceinline__ void pass_ms(gdbl* Y, long ld, int j0, int nst, int cq0, int cq1, const ldbl* Tq, ldbl* Vs) {
+  constexpr int NR = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int sc = tid >> 3, sr = tid & 7;
+  const int nms = (nst + 1) >> 1;
+  const gdbl* vsrc = Y + (long)(j0 + sc) * ld + j0 + 4 * sr;
+  const int spanel = sc >> 4, scol = sc & 15;
+  auto stage_load = [&](int m, int h) -> d4 {
+    const int s = min(2 * min(m, nms - 1) + h, nst - 1);
+    return *reinterpret_cast<const gd4*>(vsrc + 32 * s);
+  };
+  auto stage_store = [&](int m, int h, d4 v) {
+    ldbl* dst = Vs + (m & 1) * VS_STAGE2 + sc * VS_LD2 + 32 * h + 4 * sr;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rp = 64 * m + 32 * h + 4 * sr + e - 16 * spanel;
+      double a = v[e];
+      a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
+      v[e] = (rp >= 0 && 2 * m + h < nst) ? a : 0.0;
+    }
+    *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
+    *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
+  };
+  const int cq[2] = {cq0, cq1};
+  d4 w0[4][NR];
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < NR; q++) w0[p][q] = d4{0, 0, 0, 0};
+  {
+    const gdbl* cp[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + l15) * ld + j0 + 4 * g;
+    d4 v0 = stage_load(0, 0), v1 = stage_load(0, 1);
+    __syncthreads();
+    stage_store(0, 0, v0); stage_store(0, 1, v1);
+    d4 cc[NR][2];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      cc[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q]));
+      cc[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 16));
+    }
+    for (int m = 0; m < nms; m++) {
+      v0 = stage_load(m + 1, 0); v1 = stage_load(m + 1, 1);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int s = 2 * m + h;
+        const int sn = min(s + 1, nst - 1);
+        d4 cn[NR][2];
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+          cn[q][0] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn));
+          cn[q][1] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 32 * sn + 16));
+        }
+        if (h == 0) lds_barrier();
+        const ldbl* vb = Vs + (m & 1) * VS_STAGE2 + 32 * h;
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            const ldbl* vp = vb + (16 * p + l15) * VS_LD2 + 16 * rb + 4 * g;
+            const d2 va = *reinterpret_cast<const ld2*>(vp), vbb = *reinterpret_cast<const ld2*>(vp + 2);
+            const double v4[4] = {va[0], va[1], vbb[0], vbb[1]};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+              for (int q = 0; q < NR; q++) w0[p][q] = mfma(v4[e], cc[q][rb][e], w0[p][q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NR; q++) { cc[q][0] = cn[q][0]; cc[q][1] = cn[q][1]; }
+      }
+      stage_store(m + 1, 0, v0); stage_store(m + 1, 1, v1);
+    }
+  }
+  d4 w[4][NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) o = mfma(Tq[(4 * s + g) + 16 * l15], w0[p][q][s], o);
+      w[p][q] = o;
+    }
+  }
+  {
+    d4 v0 = stage_load(0, 0), v1 = stage_load(0, 1);
+    __syncthreads();
+    stage_store(0, 0, v0); stage_store(0, 1, v1);
+    gdbl* cp[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + g) * ld + j0 + 2 * l15;
+    d2 cc[NR][4];
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) cc[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld));
+    for (int m = 0; m < nms; m++) {
+      v0 = stage_load(m + 1, 0); v1 = stage_load(m + 1, 1);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int s = 2 * m + h;
+        const int sn = min(s + 1, nst - 1);
+        d2 cn[NR][4];
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) cn[q][r] = __builtin_nontemporal_load(reinterpret_cast<const gd2*>(cp[q] + (long)(4 * r) * ld + 32 * sn));
+        if (h == 0) lds_barrier();
+        if (s < nst) {
+          const ldbl* vb = Vs + (m & 1) * VS_STAGE2 + 32 * h;
+          d4 acc[NR][2];
+#pragma unroll
+          for (int q = 0; q < NR; q++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) acc[q][e] = d4{cc[q][0][e], cc[q][1][e], cc[q][2][e], cc[q][3][e]};
+#pragma unroll
+          for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) {
+              const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * VS_LD2 + 2 * l15);
+#pragma unroll
+              for (int e = 0; e < 2; e++)
+#pragma unroll
+                for (int q = 0; q < NR; q++) acc[q][e] = mfma(-w[p][q][s2], v[e], acc[q][e]);
+            }
+#pragma unroll
+          for (int q = 0; q < NR; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              __builtin_nontemporal_store(d2{acc[q][0][r], acc[q][1][r]}, reinterpret_cast<gd2*>(cp[q] + (long)(4 * r) * ld + 32 * s));
+        }
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) cc[q][r] = cn[q][r];
+      }
+      stage_store(m + 1, 0, v0); stage_store(m + 1, 1, v1);
+    }
+  }
+}
+
 template <int FL>
 __global__ void __launch_bounds__(512) k(double* Y, int ld, int rows32, int reps) {
-  __shared__ __attribute__((aligned(16))) double Vs[2 * VS_STAGE];
+  __shared__ __attribute__((aligned(16))) double Vs[2 * VS_STAGE2];
   __shared__ double T[256];
   if (threadIdx.x < 256) T[threadIdx.x] = 0.0;
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   gdbl* Yg = (gdbl*)Y + (long)blockIdx.x * ld * 336;
   for (int r = 0; r < reps; r++)
-    if (FL == 32) pass_deep<FL, true>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
+    if (FL == 128) pass_ms<FL>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
+    else if (FL == 32) pass_deep<FL, true>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
     else if (FL == 64) pass_deep<FL, false>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
     else pass<FL>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
 }
@@ -384,6 +532,7 @@ int main() {
   for (int b = 0; b < 256; b++) (void)hipMemcpy(d + (size_t)b * ld * cols, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
   for (int blocks : {1, 256}) {
     run<0>(d, ld, rows32, blocks, "as shipped");
+    run<128>(d, ld, rows32, blocks, "64-row stages (half the barriers)");
     run<32>(d, ld, rows32, blocks, "two stages of prefetch");
     run<64>(d, ld, rows32, blocks, "two stages ahead in phase A only");
     run<1>(d, ld, rows32, blocks, "no C loads/stores");
