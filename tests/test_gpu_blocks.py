@@ -26,7 +26,10 @@ def test_gemm_mfma_f64_asymmetric(M, N, K):
     assert np.abs(Cc - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()) * K
 
 
-@pytest.mark.parametrize("rows,cols", [(4, 16), (16, 16), (64, 16), (100, 37), (256, 64), (1600, 400), (80, 400), (33, 80)])
+# (672, 150), (1568, 400), (992, 464), (2048, 208): an odd number of 32-row stages (the last 64-row reflector stage of the
+# cooperative trailing pass is half empty), 4k+1 trailing tiles (odd tile updated row-parallel), the register-panel limit
+@pytest.mark.parametrize("rows,cols", [(4, 16), (16, 16), (64, 16), (100, 37), (256, 64), (1600, 400), (80, 400), (33, 80),
+                                       (672, 150), (1568, 400), (992, 464), (2048, 208)])
 def test_qr_r_only(rows, cols):
     rng = np.random.default_rng(2)
     A = np.asfortranarray(rng.standard_normal((rows, cols)))
