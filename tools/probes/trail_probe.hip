@@ -177,9 +177,8 @@ __device__ __forceinline__ void pass(gdbl* Y, long ld, int j0, int nst, int cq0,
 
 
 // Variant with a three-deep register ring: the C fragments and the V stage are requested TWO stages ahead.
-template <int FL, bool DEEPC>
+template <int FL, bool DEEPC, int NR = 2>
 __device__ __forceinline__ void pass_deep(gdbl* Y, long ld, int j0, int nst, int cq0, int cq1, const ldbl* Tq, ldbl* Vs) {
-  constexpr int NR = 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = lane >> 4, l15 = lane & 15;
   const int sc = tid >> 3, sr = tid & 7;
@@ -497,42 +496,163 @@ __device__ __forceinline__ void pass_ms(gdbl* Y, long ld, int j0, int nst, int c
   }
 }
 
+// Fused pass: phase C of the PREVIOUS block (columns jp .. jp+63, W read from `Wg`) and phase A of the CURRENT block
+// (columns j0 = jp + 64 ..) in one sweep over the rows: C is read once and written once per block instead of read twice
+// and written once.  Phase C in the non-transposed form C -= V W: the accumulator fragment (reg e of lane (g, l15) = row
+// 16 rb + 4 g + e, column l15) is the d4 a lane loads from C, and after the update it is exactly the B operand of phase A.
+// The previous block's reflectors are staged row-major with permuted panel columns (VT: [row][16 p + 4 (c % 4) + c / 4],
+// stride 66) so that the four A operands of a (row block, panel) are one 32-byte LDS read.
+constexpr int VT_LD = 66, VT_STAGE = 32 * VT_LD;
 template <int FL>
-__global__ void __launch_bounds__(512) k(double* Y, int ld, int rows32, int reps) {
+__device__ __forceinline__ void pass_fused(gdbl* Y, long ld, int jp, int nst, int cq0, int cq1, const gdbl* Wg, const ldbl* Tq,
+                                           ldbl* Vs, ldbl* Vt) {
+  constexpr int NR = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int j0 = jp + 64;
+  const int sc = tid >> 3, sr = tid & 7;
+  const gdbl* vsrcA = Y + (long)(j0 + sc) * ld + jp + 4 * sr;     // current block, rows counted from jp
+  const gdbl* vsrcT = Y + (long)(jp + sc) * ld + jp + 4 * sr;     // previous block
+  const int spanel = sc >> 4, scol = sc & 15;
+  const int pcp = 16 * spanel + 4 * (scol & 3) + (scol >> 2);
+  auto stage_load = [&](const gdbl* src, int s) -> d4 { return *reinterpret_cast<const gd4*>(src + 32 * min(s, nst - 1)); };
+  auto head = [&](d4 v, int s, int off) -> d4 {             // unit-lower-trapezoidal form, zero above the panel
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int rp = 32 * s + 4 * sr + e - off - 16 * spanel;
+      double a = v[e];
+      a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
+      v[e] = (rp >= 0) ? a : 0.0;
+    }
+    return v;
+  };
+  auto store_A = [&](int s, d4 v) {
+    v = head(v, s, 64);
+    ldbl* dst = Vs + (s & 1) * VS_STAGE + sc * VS_LD + 4 * sr;
+    *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
+    *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
+  };
+  auto store_T = [&](int s, d4 v) {
+    v = head(v, s, 0);
+    ldbl* dst = Vt + (s & 1) * VT_STAGE + (4 * sr) * VT_LD + pcp;
+#pragma unroll
+    for (int e = 0; e < 4; e++) dst[e * VT_LD] = -v[e];      // negated: the update subtracts
+  };
+  const int cq[2] = {cq0, cq1};
+  d4 w[4][NR], w0[4][NR];
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      w0[p][q] = d4{0, 0, 0, 0};
+      w[p][q] = *reinterpret_cast<const gd4*>(Wg + ((long)(cq[q] >> 4) * 4 + p) * 256 + 4 * lane);
+    }
+  gdbl* cp[NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) cp[q] = Y + (long)(cq[q] + l15) * ld + jp + 4 * g;
+  const int mrow = 4 * (l15 & 3) + (l15 >> 2);              // matrix row (in its 16-row block) behind A-operand row l15
+  d4 va = stage_load(vsrcA, 0), vt = stage_load(vsrcT, 0);
+  __syncthreads();
+  store_A(0, va); store_T(0, vt);
+  d4 cc[NR];                                                // 16 rows x 16 columns per tile, 16 rows ahead
+#pragma unroll
+  for (int q = 0; q < NR; q++) cc[q] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q]));
+  for (int s = 0; s < nst; s++) {
+    va = stage_load(vsrcA, s + 1); vt = stage_load(vsrcT, s + 1);
+#pragma unroll 1
+    for (int rb = 0; rb < 2; rb++) {
+      const int hn = min(2 * s + rb + 1, 2 * nst - 1);
+      d4 cn[NR];
+#pragma unroll
+      for (int q = 0; q < NR; q++) cn[q] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp[q] + 16 * hn));
+      if (rb == 0) lds_barrier();
+      const ldbl* vtb = Vt + (s & 1) * VT_STAGE + (16 * rb + mrow) * VT_LD + 4 * g;
+      const ldbl* vab = Vs + (s & 1) * VS_STAGE + l15 * VS_LD + 16 * rb + 4 * g;
+      // phase C of the previous block on this 16-row block
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const d2 t0 = *reinterpret_cast<const ld2*>(vtb + 16 * p), t1 = *reinterpret_cast<const ld2*>(vtb + 16 * p + 2);
+        const double v4[4] = {t0[0], t0[1], t1[0], t1[1]};
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int q = 0; q < NR; q++) cc[q] = mfma(v4[r], w[p][q][r], cc[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NR; q++) __builtin_nontemporal_store(cc[q], reinterpret_cast<gd4*>(cp[q] + 16 * (2 * s + rb)));
+      // phase A of the current block on the updated fragment
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const ldbl* vp = vab + 16 * p * VS_LD;
+        const d2 a0 = *reinterpret_cast<const ld2*>(vp), a1 = *reinterpret_cast<const ld2*>(vp + 2);
+        const double v4[4] = {a0[0], a0[1], a1[0], a1[1]};
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int q = 0; q < NR; q++) w0[p][q] = mfma(v4[e], cc[q][e], w0[p][q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NR; q++) cc[q] = cn[q];
+    }
+    store_A(s + 1, va); store_T(s + 1, vt);
+  }
+  // phase B stand-in + the W of this block to scratch
+#pragma unroll
+  for (int q = 0; q < NR; q++)
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) o = mfma(Tq[(4 * s + g) + 16 * l15], w0[p][q][s], o);
+      *reinterpret_cast<gd4*>(const_cast<gdbl*>(Wg) + ((long)(cq[q] >> 4) * 4 + p) * 256 + 4 * lane) = o;
+    }
+}
+
+template <int FL>
+__global__ void __launch_bounds__(512) k(double* Y, int ld, int rows32, int reps, double* W) {
   __shared__ __attribute__((aligned(16))) double Vs[2 * VS_STAGE2];
   __shared__ double T[256];
+  __shared__ __attribute__((aligned(16))) double Vt[2 * VT_STAGE];
   if (threadIdx.x < 256) T[threadIdx.x] = 0.0;
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  gdbl* Yg = (gdbl*)Y + (long)blockIdx.x * ld * 336;
+  gdbl* Yg = (gdbl*)Y + (long)blockIdx.x * ld * 400;
   for (int r = 0; r < reps; r++)
-    if (FL == 128) pass_ms<FL>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
+    if (FL == 512) {
+      pass_deep<FL, true, 1>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave, (const ldbl*)T, (ldbl*)Vs);
+      pass_deep<FL, true, 1>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave + 16, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
+    } else if (FL == 256) pass_fused<FL>(Yg, ld, 0, rows32 >> 5, 128 + 32 * wave, 128 + 32 * wave + 16, (const gdbl*)W + (long)blockIdx.x * 32 * 1024, (const ldbl*)T, (ldbl*)Vs, (ldbl*)Vt);
+    else if (FL == 128) pass_ms<FL>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
     else if (FL == 32) pass_deep<FL, true>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
     else if (FL == 64) pass_deep<FL, false>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
     else pass<FL>(Yg, ld, 0, rows32 >> 5, 64 + 32 * wave, 64 + 32 * wave + 16, (const ldbl*)T, (ldbl*)Vs);
 }
 
+static double* g_W = nullptr;
 template <int FL>
 void run(double* d, int ld, int rows32, int blocks, const char* what) {
   const int reps = 20;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<FL>, dim3(blocks), dim3(512), 0, 0, d, ld, rows32, 1);
+  hipLaunchKernelGGL(k<FL>, dim3(blocks), dim3(512), 0, 0, d, ld, rows32, 1, g_W);
   (void)hipDeviceSynchronize();
-  (void)hipEventRecord(e0); hipLaunchKernelGGL(k<FL>, dim3(blocks), dim3(512), 0, 0, d, ld, rows32, reps); (void)hipEventRecord(e1);
+  (void)hipEventRecord(e0); hipLaunchKernelGGL(k<FL>, dim3(blocks), dim3(512), 0, 0, d, ld, rows32, reps, g_W); (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   const double ideal = (double)(rows32 >> 5) * 4 * 64 * 64 / 2.4e6;     // ms per pass: 4 tile-stages per SIMD, 64 MFMAs of 64 cycles each
   printf("blocks %3d  %-44s %7.3f ms per pass  (MFMA-bound %.3f ms, %.0f %%)\n", blocks, what, ms / reps, ideal, 100.0 * ideal / (ms / reps));
 }
 
 int main() {
-  const int rows32 = 1600, ld = 1600, cols = 336;
+  const int rows32 = 1600, ld = 1600, cols = 400;
   double* d; (void)hipMalloc(&d, sizeof(double) * ld * cols * 256);
   std::vector<double> h((size_t)ld * cols);
   for (size_t i = 0; i < h.size(); i++) h[i] = (double)((i * 2654435761u) % 2001) / 1000.0 - 1.0;
   for (int b = 0; b < 256; b++) (void)hipMemcpy(d + (size_t)b * ld * cols, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+  (void)hipMalloc(&g_W, sizeof(double) * 32 * 1024 * 256); (void)hipMemset(g_W, 0, sizeof(double) * 32 * 1024 * 256);
   for (int blocks : {1, 256}) {
     run<0>(d, ld, rows32, blocks, "as shipped");
     run<128>(d, ld, rows32, blocks, "64-row stages (half the barriers)");
+    run<512>(d, ld, rows32, blocks, "one tile per wave, two passes, C two stages ahead");
+    run<256>(d, ld, rows32, blocks, "FUSED: C of block k-1 + A of block k (= 2 passes of MFMAs)");
     run<32>(d, ld, rows32, blocks, "two stages of prefetch");
     run<64>(d, ld, rows32, blocks, "two stages ahead in phase A only");
     run<1>(d, ld, rows32, blocks, "no C loads/stores");
