@@ -263,6 +263,72 @@ def test_sirs_q3_tree_gpu():
     assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
 
 
+def test_integer_glauber_heterogeneous_sis_and_damped_factor_gpu():
+    """The factor families of SURVEY 8(a) a18 that had only oracle-side tests: `IntegerGlauberFactor` (reference
+    test/glauber_small_tree.jl:174-318, J = [0 -1 2; ...]), `SIS_heterogeneousFactor` (test/sis_heterogeneous.jl:1-47: one
+    rate per incoming neighbour), `DampedFactor` (test/glauber_small_tree.jl:88-131, src/recursive_bp_factor.jl:183-206) -
+    the device path against brute-force enumeration and, sweep by sweep, against the oracle."""
+    # IntegerGlauber: couplings -1 / 2 on a 3-node star
+    T = 2
+    J = np.array([[0, -1, 2], [-1, 0, 0], [2, 0, 0]], float)
+    rng = np.random.default_rng(5)
+    h = rng.standard_normal(3)
+    phi = [[np.array([0.75, 0.25]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(3)]
+    w = M.glauber_factors(J != 0, J, h, 1.0, T)
+    assert isinstance(w[0][0], M.IntegerGlauberFactor)
+    bp = M.mpbp(M.IndexedBiDiGraph(J != 0), w, 2, T, phi=phi, max_bond=16)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBondThresh(15), schedule="colored")
+    obp = O.mpbp(O.IndexedBiDiGraph(J != 0), OF.glauber_factors(J != 0, J, h, 1.0, T), [2] * 3, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        pex, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, pex))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+    assert _rel(_flat(M.pair_beliefs(bp)[0]), _flat(exact_pair_marginals(obp, pex))) < 1e-9
+
+    # heterogeneous SIS: a star of 4, rates drawn per (node, neighbour), an observation at the last time
+    T = 3
+    A = np.array([[0, 1, 1, 1], [1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0]])
+    g, og = M.IndexedBiDiGraph(A), O.IndexedBiDiGraph(A)
+    rng = np.random.default_rng(0)
+    lams = [rng.random(len(og.neighbors(i))) for i in range(4)]
+    phi = [[np.array([0.5, 0.5]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(4)]
+    phi[1][T] = np.array([0.0, 1.0])
+    bp = M.mpbp(g, [[M.SIS_heterogeneousFactor(l, 0.4, 0.1)] * (T + 1) for l in lams], 2, T, phi=phi, max_bond=16)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBond(16), schedule="colored")
+    obp = O.mpbp(og, [[OF.SISHeterogeneousFactor(l, 0.4, 0.1) for _ in range(T + 1)] for l in lams], [2] * 4, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        pex, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, pex))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+    # the same model with a BINDING cap, Jacobi sweeps against the oracle's (rates differ per neighbour position: the cavity
+    # order matters)
+    bp = M.mpbp(g, [[M.SIS_heterogeneousFactor(l, 0.4, 0.1)] * (T + 1) for l in lams], 2, T, phi=phi, max_bond=3)
+    obp = O.mpbp(og, [[OF.SISHeterogeneousFactor(l, 0.4, 0.1) for _ in range(T + 1)] for l in lams], [2] * 4, T, phi=phi)
+    for _ in range(3):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(3), tol=0.0)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(3), tol=0.0, shuffle_nodes=False, jacobi=True)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL
+    assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu])) and bp.bonds().max() == 3
+
+    # DampedFactor(p = 0.3) around the homogeneous Glauber factors of the 5-node tree
+    T = 2
+    J = np.array([[0, 1, 0, 0, 0], [1, 0, 1, 1, 0], [0, 1, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 0, 0, 0]], float)
+    rng = np.random.default_rng(111)
+    h = rng.standard_normal(5)
+    phi = [[np.array([0.75, 0.25]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(5)]
+    phi[1][2] = np.array([0.0, 1.0])
+    phi[3][1] = np.array([1.0, 0.0])
+    w = [[M.DampedFactor(x, 0.3) for x in wi] for wi in M.glauber_factors(J != 0, J, h, 1.0, T)]
+    bp = M.mpbp(M.IndexedBiDiGraph(J != 0), w, 2, T, phi=phi, max_bond=16)
+    M.iterate(bp, maxiter=20, svd_trunc=M.TruncBondThresh(10), schedule="colored")
+    ow = [[OF.DampedFactor(x, 0.3) for x in wi] for wi in OF.glauber_factors(J != 0, J, h, 1.0, T)]
+    obp = O.mpbp(O.IndexedBiDiGraph(J != 0), ow, [2] * 5, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        pex, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, pex))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+
+
 def test_pair_observations_gpu():
     """reference test/pair_observations.jl: time-dependent psi on the edges."""
     T = 2
