@@ -329,6 +329,91 @@ def test_integer_glauber_heterogeneous_sis_and_damped_factor_gpu():
     assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
 
 
+def test_observe_everything_free_energy_is_logprob_gpu():
+    """reference test/sis_small_tree.jl:100-111 and test/glauber_small_tree.jl:75-86: with every (i, t) observed the
+    Bethe free energy is minus the log-probability of the observed trajectory (TruncBond(4) is not binding: every message
+    is a product state)."""
+    A, lam, rho, alpha, _, T = _sis_star_inputs()
+    X = np.array([[0, 1, 1, 0], [1, 1, 0, 0], [0, 0, 1, 1], [0, 0, 0, 1]])
+    phi = [[np.eye(2)[X[i, t]] * (0.5 if t == 0 else 1.0) for t in range(T + 1)] for i in range(4)]
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, 2, T, phi=phi, max_bond=4)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBond(4), tol=0.0, schedule="colored")
+    with np.errstate(divide="ignore"):
+        lp = M.logprob(bp, X + 1)
+    assert np.isfinite(lp) and abs(-M.bethe_free_energy(bp) - lp) < 1e-10 * abs(lp)
+    # Glauber on the 5-node tree
+    T = 2
+    J = np.array([[0, 1, 0, 0, 0], [1, 0, 1, 1, 0], [0, 1, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 0, 0, 0]], float)
+    h = np.random.default_rng(111).standard_normal(5)
+    X = np.array([[0, 1, 1], [1, 1, 0], [0, 0, 1], [1, 0, 0], [0, 1, 0]])
+    phi = [[np.eye(2)[X[i, t]] * (0.75 if (t == 0 and X[i, t] == 0) else (0.25 if t == 0 else 1.0)) for t in range(T + 1)]
+           for i in range(5)]
+    gl = M.Glauber(M.Ising(J, h, 1.0), T, phi=phi)
+    bp = gl.mpbp(max_bond=4)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncBond(4), tol=0.0, schedule="colored")
+    with np.errstate(divide="ignore"):
+        lp = M.logprob(bp, X + 1)
+    assert np.isfinite(lp) and abs(-M.bethe_free_energy(bp) - lp) < 1e-10 * abs(lp)
+
+
+def test_sis_heterogeneous_equals_homogeneous_with_binding_cap_gpu():
+    """reference test/sis_heterogeneous_compare_homogeneous.jl: `SIS_heterogeneous` with one rate everywhere against `SIS`
+    on a loopy 5-node graph, TruncBond(3) (binding), iterated to a fixed point."""
+    T, N = 3, 5
+    A = np.array([[0, 1, 1, 0, 0], [1, 0, 1, 0, 0], [1, 1, 0, 1, 0], [0, 0, 1, 0, 1], [0, 0, 0, 1, 0]])
+    lam, rho, gam = 0.15, 0.12, 0.13
+    g = M.IndexedBiDiGraph(A)
+    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    deg = A.sum(axis=0)
+    bu = M.mpbp(g, [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=3)
+    bh = M.mpbp(g, [[M.SIS_heterogeneousFactor([lam] * int(deg[i]), rho)] * (T + 1) for i in range(N)], 2, T, phi=phi, max_bond=3)
+    for b in (bu, bh):
+        M.iterate(b, maxiter=200, svd_trunc=M.TruncBond(3), tol=1e-12, schedule="sequential", shuffle_nodes=False)
+    pu, ph = _flat(M.beliefs(bu)), _flat(M.beliefs(bh))
+    assert bu.bonds().max() == 3 and _rel(ph, pu) < 1e-10
+    assert abs(M.bethe_free_energy(bu) - M.bethe_free_energy(bh)) < 1e-10
+
+
+def test_glauber_infinite_graph_equals_complete_graph_gpu():
+    """reference test/glauber_infinite_graph.jl: marginals and free energy of the infinite k-regular graph (k aliases of one
+    message, observations at t = 1 and t = T, damping 0.1, TruncThresh(0)) against BP on the complete graph of k + 1 nodes,
+    and the bipartite variant (k = (3, 2)) against the complete bipartite graph.  TruncThresh(0) keeps every non-zero
+    singular value: the cap must cover the structural bound (n_y q)^2 = 64 of the cavity trains (n_y = 4 at degree 3)."""
+    T, k, m0 = 3, 3, 0.5
+    wi = [M.HomogeneousGlauberFactor(1.0, 0.0, 1.0)] * (T + 1)
+    phi_i = [np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)]
+    phi_i[1] = np.array([0.4, 0.6])
+    phi_i[T] = np.array([0.95, 0.05])
+    bp = M.mpbp_infinite_graph(k, wi, 2, phi_i, max_bond=64)
+    M.iterate(bp, maxiter=150, svd_trunc=M.TruncThresh(0.0), tol=1e-15, damp=0.1)
+    Nc = k + 1
+    Ac = np.ones((Nc, Nc)) - np.eye(Nc)
+    bc = M.mpbp(M.IndexedBiDiGraph(Ac), [wi] * Nc, 2, T, phi=[phi_i] * Nc, max_bond=64)
+    M.iterate(bc, maxiter=150, svd_trunc=M.TruncThresh(0.0), tol=1e-15, schedule="sequential", shuffle_nodes=False)
+    assert _rel(np.array(M.beliefs(bp)[0]), np.array(M.beliefs(bc)[0])) < 1e-8
+    assert abs(M.bethe_free_energy(bp) - M.bethe_free_energy(bc) / Nc) < 1e-8
+
+    kk = (3, 2)
+    JA, JB, h = 1.0, -0.2, -0.1
+    w = [[M.HomogeneousGlauberFactor(JA, h, 1.0)] * (T + 1), [M.HomogeneousGlauberFactor(JB, h, 1.0)] * (T + 1)]
+    phi = [[np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(2)]
+    phi[0][1] = np.array([0.4, 0.6])
+    phi[1][T] = np.array([0.95, 0.05])
+    bp = M.mpbp_infinite_bipartite_graph(kk, w, (2, 2), phi, max_bond=64)
+    M.iterate(bp, maxiter=150, svd_trunc=M.TruncThresh(0.0), tol=1e-15, damp=0.1)
+    Nc = sum(kk)
+    Ac = np.zeros((Nc, Nc))
+    Ac[:kk[1], kk[1]:] = 1                       # complete_bipartite_graph(2, 3): two nodes of degree 3, three of degree 2
+    Ac = Ac + Ac.T
+    wc = [w[0] if i < kk[1] else w[1] for i in range(Nc)]
+    pc = [phi[0] if i < kk[1] else phi[1] for i in range(Nc)]
+    bc = M.mpbp(M.IndexedBiDiGraph(Ac), wc, 2, T, phi=pc, max_bond=64)
+    M.iterate(bc, maxiter=150, svd_trunc=M.TruncThresh(0.0), tol=1e-15, schedule="sequential", shuffle_nodes=False)
+    b_inf, b_c = M.beliefs(bp), M.beliefs(bc)
+    assert _rel(np.array(b_inf[0]), np.array(b_c[0])) < 1e-8 and _rel(np.array(b_inf[1]), np.array(b_c[kk[0]])) < 1e-8
+    assert abs(M.bethe_free_energy(bp) - M.bethe_free_energy(bc) / Nc) < 1e-8
+
+
 def test_pair_observations_gpu():
     """reference test/pair_observations.jl: time-dependent psi on the edges."""
     T = 2
