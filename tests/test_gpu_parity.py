@@ -434,6 +434,9 @@ def test_pair_observations_gpu():
     assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-9
     assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
     assert _rel(_flat(M.pair_beliefs(bp)[0]), _flat(exact_pair_marginals(obp, p))) < 1e-9
+    # reference test/normalizations.jl:46-51: every stored message is normalised (z = 1, the represented function sums to 1)
+    for cores in bp.get_messages():
+        assert abs(OT.normalization_log(OT.TensorTrain(cores))) < 1e-12
 
 
 def test_error_paths_do_not_abort():
