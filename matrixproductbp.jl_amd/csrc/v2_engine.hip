@@ -530,6 +530,9 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     for (int i = 0; i < P; i++) rrm = std::max(rrm, plan[i].rr_max);
     const int jac_grid_sweeps = [] { const char* e = getenv("MPBP_JACOBI_GRID_SWEEPS"); return e ? atoi(e) : 60; }();
     const int jac_grid_min = [] { const char* e = getenv("MPBP_JACOBI_GRID_MIN"); return e ? atoi(e) : 384; }();
+    // ... and only for a handful of problems: with many, one workgroup per problem keeps every CU busy and the 659
+    // launches per sweep only add latency (configs[2] shard: 498 s with the grid form on every level, 327 s without)
+    const int jac_grid_maxp = [] { const char* e = getenv("MPBP_JACOBI_GRID_MAXP"); return e ? atoi(e) : 4; }();
     const size_t svd_lds = sizeof(double) * (32 + (size_t)rrm + (rrm + 1) / 2 + 4);
     HIPCHK(c, hipFuncSetAttribute((const void*)v2::k_svd_trunc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)svd_lds));
     for (int t = 0; t < L; t++) {
@@ -567,7 +570,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       // tournament of that size takes 0.3 s per time step)
       int rrt = 1, k2t = 1;
       for (int i = 0; i < P; i++) { const int Rr = plan[i].kc[t] * probs[i].ny * q; rrt = std::max(rrt, Rr); k2t = std::max(k2t, std::min(Rr, plan[i].rdim[t + 1])); }
-      const bool jgrid = rrt <= 1024 && k2t >= jac_grid_min;
+      const bool jgrid = rrt <= 1024 && k2t >= jac_grid_min && P <= jac_grid_maxp;
       if (!jgrid) hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 0);
       else {
         hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 1);

@@ -10,8 +10,8 @@ import mpbp_amd  # noqa: E402
 
 L = mpbp_amd._lib.lib()
 dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-for rows, cols, nprob, tall in [(1600, 400, 512, 0), (1600, 400, 512, 1), (6400, 1600, 16, 0), (16384, 4096, 1, 0), (21600, 900, 16, 0)]:
-    if len(sys.argv) > 1 and str(cols) not in sys.argv[1:]:
+for rows, cols, nprob, tall in [(1600, 400, 512, 0), (1600, 400, 512, 1), (6400, 1600, 16, 0), (16384, 4096, 1, 0), (21600, 900, 16, 0), (7200, 900, 128, 0), (5400, 900, 256, 0)]:
+    if len(sys.argv) > 1 and str(cols) not in sys.argv[1:] and f"{rows}x{cols}x{nprob}" not in sys.argv[1:]:
         continue
     rng = np.random.default_rng(0)
     A1 = rng.standard_normal(rows * cols)
