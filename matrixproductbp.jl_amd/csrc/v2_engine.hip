@@ -251,6 +251,24 @@ int v2_gather_bonds(mpbp_ctx* c, const EngProb* probs, int n, std::vector<int32_
   return MPBP_OK;
 }
 
+
+// MPBP_V2_TIMING=1: device time of the batched sweeps by section (HIP events on the stream, read once per call) on stderr
+struct V2Timing {
+  bool on; hipStream_t st; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4]; hipEvent_t cur;
+  explicit V2Timing(hipStream_t s) : on(getenv("MPBP_V2_TIMING") != nullptr), st(s), cur(nullptr) {}
+  void begin() { if (on) { (void)hipEventCreate(&cur); (void)hipEventRecord(cur, st); } }
+  void end(int cat) { if (on) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev[cat].push_back({cur, e}); } }
+  void report(int P, int L) {
+    if (!on) return;
+    (void)hipStreamSynchronize(st);
+    const char* nm[4] = {"sweep 1 (assembly + QR + Lf)", "sweep 2 contractions + scaling", "sweep 2 QR of M_t", "sweep 2 Jacobi + truncation"};
+    for (int k = 0; k < 4; k++) {
+      double ms = 0;
+      for (auto& pr : ev[k]) { float x = 0; (void)hipEventElapsedTime(&x, pr.first, pr.second); ms += x; (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+      if (!ev[k].empty()) fprintf(stderr, "[v2 timing] P=%d L=%d  %-34s %10.1f ms\n", P, L, nm[k], ms);
+    }
+  }
+};
 int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const mpbp_trunc* trunc2, int* n_done, int* did_sweep2) {
   *did_sweep2 = 0;
   *n_done = 0;
@@ -420,6 +438,8 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
   const bool force_tall = [] { const char* e = getenv("MPBP_DEBUG_FORCE_TALL"); return e && e[0] == '1'; }();
   // ---- the time steps
   std::vector<QrDims> dims(P);
+  V2Timing tm(st);
+  tm.begin();
   for (int t = L - 1; t >= 1; t--) {
     int maxN1 = 0, maxN2 = 0, rows32m = 0, colsm = 0; int64_t maxE = 0;
     for (int i = 0; i < P; i++) {
@@ -439,10 +459,11 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     hipLaunchKernelGGL(v2::k_maxabs, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
     hipLaunchKernelGGL(v2::k_lf_write, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), (const v2::LfDesc*)(dl + o), lay);
   }
+  tm.end(0);
   HIPCHK(c, hipGetLastError());
   for (int i = 0; i < P; i++) { probs[i].lf = bf[i].lf; probs[i].lfoff = bf[i].lfoff; probs[i].rdim = bf[i].rdim; }
   *n_done = P;
-  if (!trunc2) return MPBP_OK;
+  if (!trunc2) { tm.report(P, L); return MPBP_OK; }
   // ================================================================ the truncating sweep on the grid
   {
     std::vector<v2::GemmDesc> gn1((size_t)P * L), gn2((size_t)P * L * q), gmt((size_t)P * L), gcr((size_t)P * L);
@@ -552,6 +573,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
         }
       }
       const size_t o = (size_t)t * P;
+      tm.begin();
       hipLaunchKernelGGL(v2::k_build_E, dim3((unsigned)std::min<int64_t>(64, (maxE + 255) / 256), P), dim3(256), 0, st, (const v2::EDesc*)(de + o));
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN1 + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dn1 + o));
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN2 + 127) / 128), P * q), dim3(512), 0, st, (const v2::GemmDesc*)(dn2 + o * q));
@@ -560,14 +582,17 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       hipLaunchKernelGGL(v2::k_scale, dim3(gsc, P), dim3(256), 0, st, (const v2::ScaleDesc*)(dsc + o), c->d_stats);
       if (t == L - 1) {
         hipLaunchKernelGGL(v2::k_lastcore, dim3(P), dim3(256), 0, st, (const v2::LastDesc*)dlast);
+        tm.end(1);
         break;
       }
       hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq2 + o), lay);
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNm + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dmt + o));
+      tm.end(1); tm.begin();
       if (qr_batch(st, dq2 + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
       // the SVD of the triangular factor: inside one workgroup, or - factors of several hundred columns - as rounds of
       // rotations over the grid (659 launches per sweep at 660 columns: 20+ workgroups rotate at once, a one-workgroup
       // tournament of that size takes 0.3 s per time step)
+      tm.end(2); tm.begin();
       int rrt = 1, k2t = 1;
       for (int i = 0; i < P; i++) { const int Rr = plan[i].kc[t] * probs[i].ny * q; rrt = std::max(rrt, Rr); k2t = std::max(k2t, std::min(Rr, plan[i].rdim[t + 1])); }
       const bool jgrid = rrt <= 1024 && k2t >= jac_grid_min && P <= jac_grid_maxp;
@@ -591,12 +616,15 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
         }
         hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 2);
       }
+      tm.end(3); tm.begin();
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNc + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dcr + o));
+      tm.end(1);
     }
     hipLaunchKernelGGL(v2::k_normalize_out, dim3(P), dim3(256), 0, st, (const v2::NormDesc*)dnrm, c->d_stats);
     HIPCHK(c, hipGetLastError());
     // the host vectors of this block must outlive the copies: they were synchronised above
     *did_sweep2 = 1;
   }
+  tm.report(P, L);
   return MPBP_OK;
 }
