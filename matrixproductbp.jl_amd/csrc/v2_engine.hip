@@ -70,8 +70,8 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
         else
           for (int jj = 0; jj <= 16; jj++)
             hipLaunchKernelGGL(v2::k_colstep, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jp, jj, p);
-        hipLaunchKernelGGL(v2::k_gram, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jb, p);
-        hipLaunchKernelGGL(v2::k_build_T, dim3(P), dim3(64), 0, st, d_probs, lay, jb, p);
+        hipLaunchKernelGGL(v2::k_gram, dim3(nchunk * v2::GSUB, P), dim3(512), 0, st, d_probs, lay, jb, p);
+        hipLaunchKernelGGL(v2::k_build_T, dim3(P), dim3(256), 0, st, d_probs, lay, jb, p);
       } else {
         hipLaunchKernelGGL(v2::k_fpanel, dim3(P), dim3(512), v2::fpanel_lds_bytes(p), st, d_probs, lay, jb, p);
       }

@@ -26,6 +26,7 @@ namespace v2 {
 using namespace v512::wg;
 
 constexpr int CH = 2048;          // rows per chunk (512 threads x 4 rows for the column steps; 64 stages of 32 rows for the updates)
+constexpr int GSUB = 4;           // the Gram pass splits a chunk over GSUB workgroups (one or two problems: bandwidth of more CUs)
 
 struct QrProb {
   double* Y;                      // column-major, ld % 32 == 0; see the padding contract above
@@ -48,13 +49,13 @@ __host__ __device__ inline AuxLay make_auxlay(int nchunk, int ntile) {
   a.mx = o; o += 16;
   a.bar = o; o += 16;            // 17 int32 arrival counters of the cooperative column steps (+ padding)
   a.part = o; o += (int64_t)nchunk * 256;
-  a.gram = o; o += (int64_t)nchunk * 4 * 256;
+  a.gram = o; o += (int64_t)nchunk * GSUB * 4 * 256;
   a.w0 = o; o += (int64_t)ntile * nchunk * 4 * 4 * 256;
   (void)o;
   return a;
 }
 __host__ __device__ inline int64_t auxlay_doubles(int nchunk, int ntile) {
-  return 4 * 256 + 6 * 256 + 64 + 256 + 16 + 16 + (int64_t)nchunk * 256 + (int64_t)nchunk * 1024 + (int64_t)ntile * nchunk * 4096;
+  return 4 * 256 + 6 * 256 + 64 + 256 + 16 + 16 + (int64_t)nchunk * 256 + (int64_t)nchunk * GSUB * 1024 + (int64_t)ntile * nchunk * 4096;
 }
 
 __device__ __forceinline__ double sel16(const double (&v)[16], int j) {
@@ -488,13 +489,13 @@ __global__ void __launch_bounds__(256, NT == 1 ? 3 : 2) k_trail4f(const QrProb* 
 
 // ------------------------------------------------------------------------------------------------------------------
 // Gram blocks of the freshly factored panel x (index pidx of the block at column jb) against itself and the earlier
-// panels of its block:  G_0 = Vx^T Vx,  G_k = Vx^T V_{k-1} (k = 1..pidx), rows of one chunk.  grid (nchunk, nprob).
+// panels of its block:  G_0 = Vx^T Vx,  G_k = Vx^T V_{k-1} (k = 1..pidx), rows of a quarter chunk.  grid (nchunk * GSUB, nprob).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512) k_gram(const QrProb* probs, AuxLay lay, int jb, int pidx) {
   const QrProb P = probs[blockIdx.y];
   const int jx = jb + 16 * pidx;
   if (jx >= P.kmax) return;
-  const int chunk = blockIdx.x;
+  const int chunk = blockIdx.x / GSUB, sub = blockIdx.x % GSUB;
   const int rows32 = (P.rows + 31) & ~31;
   const int cfirst = jx / CH, clast = (rows32 - 1) / CH;
   if (chunk < cfirst || chunk > clast) return;
@@ -506,7 +507,8 @@ __global__ void __launch_bounds__(512) k_gram(const QrProb* probs, AuxLay lay, i
   const int np = pidx + 1;
   __shared__ double big_[8 * 1024];
   ldbl* big = (ldbl*)big_;
-  const int rb0 = max(chunk * CH, jx) >> 4, rb1 = min((chunk + 1) * CH, rows32) >> 4;
+  const int r0 = chunk * CH + sub * (CH / GSUB);
+  const int rb0 = max(r0, jx) >> 4, rb1 = min(r0 + CH / GSUB, rows32) >> 4;        // may be empty: zeros are written
   d4 acc[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) acc[k] = d4{0, 0, 0, 0};
@@ -546,17 +548,19 @@ __global__ void __launch_bounds__(512) k_gram(const QrProb* probs, AuxLay lay, i
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < 8; w++) s += big[w * 1024 + idx];
-    aux[lay.gram + (long)chunk * 1024 + idx] = s;
+    aux[lay.gram + (long)(chunk * GSUB + sub) * 1024 + idx] = s;
   }
 }
 
-// T of the panel from its Gram block and taus, cross Grams S_pr of the block; grid (nprob), 64 threads
-__global__ void __launch_bounds__(64) k_build_T(const QrProb* probs, AuxLay lay, int jb, int pidx) {
+// T of the panel from its Gram block and taus, cross Grams S_pr of the block; grid (nprob), 256 threads: one entry of
+// the (up to four) 16x16 blocks per thread, the partial sums of the row chunks in four independent chains so that the
+// loads overlap (as 64 threads with one serial chain per entry this launch took 22 us for 1 us of work)
+__global__ void __launch_bounds__(256) k_build_T(const QrProb* probs, AuxLay lay, int jb, int pidx) {
   const QrProb P = probs[blockIdx.x];
   const int jx = jb + 16 * pidx;
   if (jx >= P.kmax) return;
   const int rows32 = (P.rows + 31) & ~31;
-  const int cfirst = jx / CH, clast = (rows32 - 1) / CH;
+  const int cfirst = jx / CH, cl = (rows32 - 1) / CH;
   const int tid = threadIdx.x;
   gdbl* aux = (gdbl*)P.aux;
   __shared__ double g_[256 + 16 + 256];
@@ -564,18 +568,29 @@ __global__ void __launch_bounds__(64) k_build_T(const QrProb* probs, AuxLay lay,
   ldbl* tau = G + 256;
   ldbl* Ts = tau + 16;
   const int np = pidx + 1;
-  for (int k = 0; k < np; k++) {
-    for (int idx = tid; idx < 256; idx += 64) {
-      double s = 0.0;
-      for (int cc = cfirst; cc <= clast; cc++) s += aux[lay.gram + (long)cc * 1024 + 256 * k + idx];
-      if (k == 0) G[idx] = s;
-      else aux[lay.S + (long)(pidx * (pidx - 1) / 2 + (k - 1)) * 256 + idx] = s;
+  double sk[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (k < np) {
+      const gdbl* src = aux + lay.gram + 256 * k + tid;
+      int cc = cfirst * GSUB;
+      const int clast = cl * GSUB + GSUB - 1;
+      for (; cc + 3 <= clast; cc += 4) {
+        s0 += src[(long)cc * 1024]; s1 += src[(long)(cc + 1) * 1024]; s2 += src[(long)(cc + 2) * 1024]; s3 += src[(long)(cc + 3) * 1024];
+      }
+      for (; cc <= clast; cc++) s0 += src[(long)cc * 1024];
     }
+    sk[k] = (s0 + s1) + (s2 + s3);
   }
+  G[tid] = sk[0];
+#pragma unroll
+  for (int k = 1; k < 4; k++)
+    if (k < np) aux[lay.S + (long)(pidx * (pidx - 1) / 2 + (k - 1)) * 256 + tid] = sk[k];
   if (tid < 16) tau[tid] = aux[lay.tau + pidx * 16 + tid];
   __syncthreads();
   qr_T_from_gram(G, tau, 16, Ts);
-  for (int idx = tid; idx < 256; idx += 64) aux[lay.T + pidx * 256 + idx] = Ts[idx];
+  aux[lay.T + pidx * 256 + tid] = Ts[tid];
   if (tid < 32) ((int*)(P.aux + lay.bar))[tid] = 0;          // arrival counters of the next cooperative panel
 }
 
