@@ -52,14 +52,16 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
             default: hipLaunchKernelGGL(v2::k_inblock<3>, dim3(P), dim3(512), 0, st, d_probs, lay, jb); break;
           }
         } else {
-          const dim3 g(1, nchunk, P);
+          // few problems: a quarter chunk per workgroup (tw = 0, grid.x = 4); many: a chunk per workgroup (tw = 1)
+          const int twi = ((int64_t)nchunk * P <= 128) ? 0 : 1;
+          const dim3 g(twi == 0 ? 4 : 1, nchunk, P);
           switch (p) {
-            case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0);
-                    hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0); break;
-            case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0);
-                    hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0); break;
-            default: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0);
-                     hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, 1, 0); break;
+            case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0);
+                    hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0); break;
+            case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0);
+                    hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0); break;
+            default: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0);
+                     hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0); break;
           }
         }
       }

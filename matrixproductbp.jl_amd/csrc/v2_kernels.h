@@ -622,13 +622,18 @@ __global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay,
   const TrailGeom G = trail_geom(P, jb, NP, inblock != 0);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
-  const int rw = 4 / tw;
-  const int tile = blockIdx.x * tw + (wave % tw), rsub = wave / tw;
+  // tw = 0: ONE tile (the left-looking update inside a block), a quarter chunk per workgroup and a quarter of that per
+  // wave (grid.x = 4): four times the workgroups of the tw = 1 form, whose waves walked 512 rows each with one problem
+  // on the chip; the four waves' products are summed through LDS into the same slot layout (chunk * 4 + quarter)
+  const bool fine = tw == 0;
+  const int rw = fine ? 4 : 4 / tw;
+  const int tile = fine ? 0 : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)blockIdx.x : wave / tw;
   if (tile >= G.ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
   const int sub = CH / rw;                                 // rows per sub-chunk (multiple of 32)
-  const int ra = max(chunk * CH + rsub * sub, jb), rbnd = min(chunk * CH + (rsub + 1) * sub, rows32);
+  const int wsub = fine ? sub / 4 : sub, woff = fine ? wave * wsub : 0;
+  const int ra = max(chunk * CH + rsub * sub + woff, jb), rbnd = min(chunk * CH + rsub * sub + woff + wsub, rows32);
   const gdbl* Y = (const gdbl*)P.Y;
   gdbl* aux = (gdbl*)P.aux;
   const long ld = P.ld;
@@ -658,6 +663,18 @@ __global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay,
     }
   }
   gdbl* w0 = aux + lay.w0 + ((long)tile * (lay.nchunk * 4) + chunk * 4 + rsub) * 1024;
+  if (fine) {
+    __shared__ double ws_[4 * NP * 256];
+    ldbl* ws = (ldbl*)ws_;
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) ws[(wave * NP + p) * 256 + (g + 4 * r) + 16 * l15] = acc[p][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NP * 256; i += 256)
+      w0[i] = (ws[i] + ws[NP * 256 + i]) + (ws[2 * NP * 256 + i] + ws[3 * NP * 256 + i]);
+    return;
+  }
 #pragma unroll
   for (int p = 0; p < NP; p++)
 #pragma unroll
@@ -682,13 +699,15 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
   for (int i = tid; i < 4 * 256; i += 256) Tq[i] = aux[lay.T + i];
   for (int i = tid; i < 6 * 256; i += 256) Sq[i] = aux[lay.S + i];
   __syncthreads();
-  const int rw = 4 / tw;
-  const int tile = blockIdx.x * tw + (wave % tw), rsub = wave / tw;
+  const bool fine = tw == 0;                               // see k_trailW
+  const int rw = fine ? 4 : 4 / tw;
+  const int tile = fine ? 0 : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)blockIdx.x : wave / tw;
   if (tile >= G.ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
   const int sub = CH / rw;
-  const int ra = max(chunk * CH + rsub * sub, jb & ~31), rbnd = min(chunk * CH + (rsub + 1) * sub, rows32);
+  const int wsub = fine ? sub / 4 : sub, woff = fine ? wave * wsub : 0;
+  const int ra = max(chunk * CH + rsub * sub + woff, jb & ~31), rbnd = min(chunk * CH + rsub * sub + woff + wsub, rows32);
   if (ra >= rbnd) return;
   const int cb0 = G.c0 + 16 * tile;
   // partial products of every slot that took part: chunks from the one holding row jb, all 4 / rw... sub-chunks
