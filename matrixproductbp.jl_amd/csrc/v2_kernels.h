@@ -231,82 +231,90 @@ __global__ void __launch_bounds__(512) k_colsteps_coop(const QrProb* probs, AuxL
 #pragma unroll
     for (int c = 0; c < 16; c++) { const double v = Y[(long)(jp + c) * ld + rc]; Pn[s][c] = rv[s] ? v : 0.0; }
   }
-  for (int jj = 0; jj <= 16; jj++) {
-    if (jj >= 1) {
-      const int j = jj - 1;
+  // One column step with the column index a compile-time constant (the 17 steps are written out below): the panel slice
+  // is then indexed statically - no 16-way selects - and columns left of the current one are skipped (as a run-time loop
+  // the arithmetic of a step took as long as its hand-off).
+  auto step = [&](auto jjc) {
+    constexpr int jj = decltype(jjc)::value;
+    if constexpr (jj >= 1) {
+      constexpr int j = jj - 1;
       double tot[16], rowv[16];          // left in LDS by wave 0 after the hand-off of step j
 #pragma unroll
-      for (int c = 0; c < 16; c++) { tot[c] = ex[c]; rowv[c] = ex[16 + c]; }
-      const double ss = sel16(tot, j), alpha = sel16(rowv, j);
+      for (int c = j; c < 16; c++) { tot[c] = ex[c]; rowv[c] = ex[16 + c]; }
       double beta, tj, scale;
-      larfg(alpha, ss, beta, tj, scale);
+      larfg(rowv[j], tot[j], beta, tj, scale);
       double tw[16];
 #pragma unroll
-      for (int c = 0; c < 16; c++) tw[c] = (c > j) ? tj * (rowv[c] + scale * tot[c]) : 0.0;
+      for (int c = j + 1; c < 16; c++) tw[c] = tj * (rowv[c] + scale * tot[c]);
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         const int r = chunk * CH + tid + 512 * s;
         const bool below = rv[s] && r > jp + j, pivot = r == jp + j;
-        const double xj = sel16(Pn[s], j);
+        const double xj = Pn[s][j];
         const double v = below ? xj * scale : (pivot ? 1.0 : 0.0);
-        const double nxj = below ? v : (pivot ? beta : xj);
+        Pn[s][j] = below ? v : (pivot ? beta : xj);
 #pragma unroll
-        for (int c = 0; c < 16; c++) Pn[s][c] = (c == j) ? nxj : Pn[s][c] - tw[c] * v;
+        for (int c = j + 1; c < 16; c++) Pn[s][c] -= tw[c] * v;
       }
       if (chunk == cfirst && tid == 0) aux[lay.tau + pidx * 16 + j] = tj;
     }
-    if (jj == 16) break;
-    double vals[16];
+    if constexpr (jj < 16) {
+      double vals[16];
 #pragma unroll
-    for (int c = 0; c < 16; c++) vals[c] = 0.0;
+      for (int c = 0; c < 16; c++) vals[c] = 0.0;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const int r = chunk * CH + tid + 512 * s;
-      const bool below = rv[s] && r > jp + jj;
-      const double x = below ? sel16(Pn[s], jj) : 0.0;
+      for (int s = 0; s < 4; s++) {
+        const int r = chunk * CH + tid + 512 * s;
+        const bool below = rv[s] && r > jp + jj;
+        const double x = below ? Pn[s][jj] : 0.0;
 #pragma unroll
-      for (int c = 0; c < 16; c++) vals[c] += x * Pn[s][c];
-      if (r == jp + jj) {
+        for (int c = jj; c < 16; c++) vals[c] += x * Pn[s][c];
+        if (r == jp + jj) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) st_sc1(aux + lay.piv + jj * 16 + c, Pn[s][c]);
-      }
-    }
-    int idx;
-    const double wsum = wave_sum16(vals, lane, idx);
-    if ((lane & 3) == 0) red[wave * 16 + idx] = wsum;
-    __syncthreads();
-    if (tid < 16) {
-      double s = 0.0;
-#pragma unroll
-      for (int w = 0; w < 8; w++) s += red[w * 16 + tid];
-      st_sc1(aux + lay.part + ((long)chunk * 16 + jj) * 16 + tid, s);
-    }
-    // ---- arrival: every (write-through) store of this workgroup is out, then lane 0 signals and waits for the others
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (wave == 0) {
-      if (lane == 0) {
-        __hip_atomic_fetch_add(&bar[jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(&bar[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
-          if (++spins > (1 << 21)) { __hip_atomic_store(gerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-          __builtin_amdgcn_s_sleep(4);
+          for (int c = 0; c < 16; c++) st_sc1(aux + lay.piv + jj * 16 + c, Pn[s][c]);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the loads below behind the poll
-      // the polling wave reads every handed-off byte with sc1 loads (L2 / memory, never this CU's L1) and leaves the
-      // column totals and the pivot row in LDS for the other waves: fixed summation order (chunks 4 apart per lane group,
-      // then the groups)
-      const int c = lane & 15, sub = lane >> 4;
-      double s = 0.0;
-      for (int cc = cfirst + sub; cc <= clast; cc += 4) s += ld_sc1(aux + lay.part + ((long)cc * 16 + jj) * 16 + c);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      const double pv = ld_sc1(aux + lay.piv + jj * 16 + c);
-      if (lane < 16) { ex[c] = s; ex[16 + c] = pv; }
+      int idx;
+      const double wsum = wave_sum16(vals, lane, idx);
+      if ((lane & 3) == 0) red[wave * 16 + idx] = wsum;
+      __syncthreads();
+      if (tid < 16) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) s += red[w * 16 + tid];
+        st_sc1(aux + lay.part + ((long)chunk * 16 + jj) * 16 + tid, s);
+      }
+      // ---- arrival: every (write-through) store of this workgroup is out, then lane 0 signals and waits for the others
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (wave == 0) {
+        if (lane == 0) {
+          __hip_atomic_fetch_add(&bar[jj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while (__hip_atomic_load(&bar[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
+            if (++spins > (1 << 21)) { __hip_atomic_store(gerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(4);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the loads below behind the poll
+        // the polling wave reads every handed-off byte with sc1 loads (L2 / memory, never this CU's L1) and leaves the
+        // column totals and the pivot row in LDS for the other waves: fixed summation order (chunks 4 apart per lane
+        // group, then the groups)
+        const int c = lane & 15, sub = lane >> 4;
+        double s = 0.0;
+        for (int cc = cfirst + sub; cc <= clast; cc += 4) s += ld_sc1(aux + lay.part + ((long)cc * 16 + jj) * 16 + c);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const double pv = ld_sc1(aux + lay.piv + jj * 16 + c);
+        if (lane < 16) { ex[c] = s; ex[16 + c] = pv; }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-  }
+  };
+#define MPBP_STEP(J) step(std::integral_constant<int, J>{});
+  MPBP_STEP(0) MPBP_STEP(1) MPBP_STEP(2) MPBP_STEP(3) MPBP_STEP(4) MPBP_STEP(5) MPBP_STEP(6) MPBP_STEP(7) MPBP_STEP(8)
+  MPBP_STEP(9) MPBP_STEP(10) MPBP_STEP(11) MPBP_STEP(12) MPBP_STEP(13) MPBP_STEP(14) MPBP_STEP(15) MPBP_STEP(16)
+#undef MPBP_STEP
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const int r = chunk * CH + tid + 512 * s;
