@@ -67,9 +67,14 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       }
       if (tall) {
         // every row-chunk workgroup resident at once: one launch with arrival counters; else one launch per column
-        if (coop_err && (int64_t)nchunk * P <= coop_max_wgs && !getenv("MPBP_DEBUG_NO_COOP_PANEL"))
-          hipLaunchKernelGGL(v2::k_colsteps_coop, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jp, p, coop_err);
-        else
+        // (the cooperative kernel needs all the row-chunk workgroups of a problem resident together: a batch too large
+        // for that goes through it in groups of problems, as long as that takes fewer launches than the 17 column steps)
+        static const bool no_coop = getenv("MPBP_DEBUG_NO_COOP_PANEL") != nullptr;
+        const int pb = (nchunk > 0) ? coop_max_wgs / nchunk : 0;          // problems per cooperative launch
+        if (coop_err && !no_coop && pb >= 1 && (P + pb - 1) / pb <= 8) {
+          for (int p0 = 0; p0 < P; p0 += pb)
+            hipLaunchKernelGGL(v2::k_colsteps_coop, dim3(nchunk, std::min(pb, P - p0)), dim3(512), 0, st, d_probs + p0, lay, jp, p, coop_err);
+        } else
           for (int jj = 0; jj <= 16; jj++)
             hipLaunchKernelGGL(v2::k_colstep, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jp, jj, p);
         hipLaunchKernelGGL(v2::k_gram, dim3(nchunk * v2::GSUB, P), dim3(512), 0, st, d_probs, lay, jb, p);
