@@ -716,15 +716,42 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
   const int sub = CH / rw;
   const int wsub = fine ? sub / 4 : sub, woff = fine ? wave * wsub : 0;
   const int ra = max(chunk * CH + rsub * sub + woff, jb & ~31), rbnd = min(chunk * CH + rsub * sub + woff + wsub, rows32);
-  if (ra >= rbnd) return;
+  if (!fine && ra >= rbnd) return;
   const int cb0 = G.c0 + 16 * tile;
   // partial products of every slot that took part: chunks from the one holding row jb, all 4 / rw... sub-chunks
   const int cfirst = jb / CH, clast = (rows32 - 1) / CH;
+  // fine form: the four waves of the workgroup (same tile) share the sum over the slots - slots 4 apart per wave, the four
+  // partial sums through LDS in a fixed order - instead of every wave walking all of them
+  __shared__ double wsum_[4 * NP * 256];
+  ldbl* wsum = (ldbl*)wsum_;
+  if (fine) {
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      d4 t = d4{0, 0, 0, 0};
+      if (p < G.np)
+        for (int sl = cfirst * 4 + wave; sl <= clast * 4 + 3; sl += 4) {
+          const gdbl* w0 = aux + lay.w0 + ((long)tile * (lay.nchunk * 4) + sl) * 1024 + 256 * p;      // every slot was written
+#pragma unroll
+          for (int r = 0; r < 4; r++) t[r] += w0[(g + 4 * r) + 16 * l15];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; r++) wsum[(wave * NP + p) * 256 + (g + 4 * r) + 16 * l15] = t[r];
+    }
+  }
+  if (fine) __syncthreads();          // uniform: `fine` is a launch parameter, and no wave of a fine workgroup has left
+  if (ra >= rbnd) return;
   d4 w[NP];
 #pragma unroll
   for (int p = 0; p < NP; p++) {
     d4 t = d4{0, 0, 0, 0};
     if (p < G.np) {
+      if (fine) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int o = p * 256 + (g + 4 * r) + 16 * l15;
+          t[r] = (wsum[o] + wsum[NP * 256 + o]) + (wsum[2 * NP * 256 + o] + wsum[3 * NP * 256 + o]);
+        }
+      } else
       for (int cc = cfirst; cc <= clast; cc++)
         for (int rs = 0; rs < rw; rs++) {
           // sub-chunks entirely above row jb or below the matrix wrote nothing: skip them exactly as k_trailW did
