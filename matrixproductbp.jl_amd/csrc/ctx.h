@@ -81,6 +81,7 @@ struct mpbp_ctx {
   std::vector<int64_t> pyy_base;   // per node: offset of prob_yy blob
   Arena arena, scratch, v2arena;   // work trains of a sweep / engine slots + launch records / batched gauge sweep
   int num_cu = 256;
+  bool no_coop_panel = false;   // set after a cooperative panel launch timed out: the column steps then run as separate launches
   int profiling = 0;            // 0 off, 1 HIP-event timing of the cavity launches, 2 also the in-kernel phase timers
   std::string err;
   mpbp_stats last{};
@@ -93,10 +94,16 @@ struct mpbp_ctx {
   int nnz() const { return nbr_ptr[N]; }
   double* slot_cores(int e) const { return d_cores + (int64_t)slot_of_edge[e] * slot_doubles; }
   int32_t* slot_bonds(int e) const { return d_bonds + (int64_t)slot_of_edge[e] * (L + 1); }
-  // incoming messages of a pass: the live slab, or the snapshot of a split Jacobi sweep (mpbp_sweep)
+  // incoming messages of a pass: the live slab, or the snapshot of a split Jacobi sweep (mpbp_sweep).  The snapshot is
+  // compact: it holds the in-edges of the listed nodes only, snap_index[e] = position of edge e in it (or -1).
   double* snap_cores = nullptr; int32_t* snap_bonds = nullptr;
-  const double* read_slot_cores(int e) const { return (snap_cores ? snap_cores : d_cores) + (int64_t)slot_of_edge[e] * slot_doubles; }
-  const int32_t* read_slot_bonds(int e) const { return (snap_bonds ? snap_bonds : d_bonds) + (int64_t)slot_of_edge[e] * (L + 1); }
+  std::vector<int32_t> snap_index;
+  const double* read_slot_cores(int e) const {
+    return snap_cores ? snap_cores + (int64_t)snap_index[e] * slot_doubles : d_cores + (int64_t)slot_of_edge[e] * slot_doubles;
+  }
+  const int32_t* read_slot_bonds(int e) const {
+    return snap_bonds ? snap_bonds + (int64_t)snap_index[e] * (L + 1) : d_bonds + (int64_t)slot_of_edge[e] * (L + 1);
+  }
 };
 
 // grows an arena (contents are NOT preserved); used between launches only

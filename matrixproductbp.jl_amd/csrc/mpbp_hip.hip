@@ -532,18 +532,31 @@ static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool 
                     2.0 * (double)bmact * (double)bmact * pl.capout * pl.ny * pl.q >= 2e8;
       if (const char* s2 = getenv("MPBP_SWEEP2")) { if (!strcmp(s2, "grid")) s2grid = trunc.kind == MPBP_TRUNC_BOND || trunc.kind == MPBP_TRUNC_BOND_MAX; else if (!strcmp(s2, "wg")) s2grid = false; }
       int did2 = 0;
-      int rc = v2_gauge_sweep(c, sorted.data() + done, nprob - done, hb.data() + (size_t)done * 2 * (c->L + 1), s2grid ? &trunc : nullptr, &nd, &did2);
-      if (rc != MPBP_OK) return rc;
-      if (!did2) {
-        rc = run(sorted.data() + done, nd);
+      // The cooperative panel kernel (k_colsteps_coop) assumes that this process owns the GPU: its row-chunk workgroups
+      // wait for each other inside one launch.  If they are not co-resident (a second process or stream on the device)
+      // an arrival counter times out; the kernel then leaves Y untouched and raises a flag.  Nothing of a batch is
+      // committed to the message slab before this point (products live in the work arena), so the batch is simply
+      // repeated with one launch per column step, and the context stays in that mode.
+      for (int attempt = 0;; attempt++) {
+        EngStats sbak;
+        const bool may_retry = !c->no_coop_panel;
+        if (may_retry) HIPCHK(c, hipMemcpyAsync(&sbak, c->d_stats, sizeof sbak, hipMemcpyDeviceToHost, c->stream));
+        int rc = v2_gauge_sweep(c, sorted.data() + done, nprob - done, hb.data() + (size_t)done * 2 * (c->L + 1), s2grid ? &trunc : nullptr, &nd, &did2);
         if (rc != MPBP_OK) return rc;
-      }
-      // the triangular factors live in c->v2arena until sweep 2 has consumed them
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      {
+        if (!did2) {
+          rc = run(sorted.data() + done, nd);
+          if (rc != MPBP_OK) return rc;
+        }
+        // the triangular factors live in c->v2arena until sweep 2 has consumed them
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         int herr = 0;
         HIPCHK(c, hipMemcpy(&herr, c->d_counter + 8, sizeof(int), hipMemcpyDeviceToHost));
-        if (herr) return c->fail(MPBP_EHIP, "batched gauge sweep: an arrival counter of the cooperative panel kernel timed out (workgroups not co-resident?); rerun with MPBP_DEBUG_NO_COOP_PANEL=1");
+        const bool inject = getenv("MPBP_DEBUG_COOP_FAIL_ONCE") != nullptr;            // test hook: pretend the first attempt timed out
+        if (inject && may_retry && attempt == 0) herr = 1;
+        if (!herr) break;
+        if (!may_retry) return c->fail(MPBP_EHIP, "batched gauge sweep: arrival counter timed out although the cooperative panel kernel was not used");
+        c->no_coop_panel = true;
+        HIPCHK(c, hipMemcpy(c->d_stats, &sbak, sizeof sbak, hipMemcpyHostToDevice));    // the repeated batch counts once
       }
       done += nd;
     }
@@ -642,6 +655,13 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
     int64_t stride = ((int64_t)s.cap * s.cap * s.ny * s.qphys + 3) & ~int64_t(3);
     return std::pair<int64_t, int64_t>(stride, stride * L);
   };
+  if (may_split && n_nodes > 1) {
+    // MPBP_DEBUG_SPLIT_NODES=k: take the split path whenever a pass lists more than k nodes (tests of the snapshot logic;
+    // read on every call so that a test can switch it)
+    const char* e = getenv("MPBP_DEBUG_SPLIT_NODES");
+    const int dbg_split = e ? atoi(e) : 0;
+    if (dbg_split > 0 && n_nodes > dbg_split) return MPBP_ESPLIT_INTERNAL;
+  }
   for (int pass = 0; pass < 2; pass++) {
     c->arena.reset();
     bool ok = true;
@@ -979,14 +999,27 @@ extern "C" int mpbp_sweep(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mp
   int rc = sweep_nodes(c, nodes, n_nodes, trunc, damp, &st, true);
   if (rc == MPBP_ESPLIT_INTERNAL) {
     // The listed nodes are updated from the messages at entry (Jacobi semantics of one call): the halves read a
-    // snapshot of the slab, so that the split is invisible in the results.
-    const size_t cb = sizeof(double) * (size_t)c->slot_doubles * c->nslots, bb = sizeof(int32_t) * (size_t)(c->L + 1) * c->nslots;
+    // snapshot, so that the split is invisible in the results.  Only the in-edges of the listed nodes are read by a pass
+    // (prep), so only their slots are copied - the snapshot is allocated exactly when memory is short, and a copy of the
+    // whole slab (24 GB at configs[2]) could be what does not fit.
+    c->snap_index.assign(c->slot_of_edge.size(), -1);
+    std::vector<int> ins;
+    for (int k = 0; k < n_nodes; k++)
+      for (int p = c->nbr_ptr[nodes[k]]; p < c->nbr_ptr[nodes[k] + 1]; p++) {
+        const int e = c->in_edge[p];
+        if (c->snap_index[e] < 0) { c->snap_index[e] = (int32_t)ins.size(); ins.push_back(e); }
+      }
+    const size_t nin = std::max<size_t>(ins.size(), 1);
+    const size_t cb = sizeof(double) * (size_t)c->slot_doubles * nin, bb = sizeof(int32_t) * (size_t)(c->L + 1) * nin;
     void* snap = nullptr;
     hipError_t e = hipMalloc(&snap, cb + bb + 256);
     if (e != hipSuccess) return c->fail(MPBP_ENOMEM, "hipMalloc(%zu MiB message snapshot for a split sweep) failed", (cb + bb) >> 20);
-    hipMemcpyAsync(snap, c->d_cores, cb, hipMemcpyDeviceToDevice, c->stream);
-    hipMemcpyAsync((char*)snap + ((cb + 255) & ~size_t(255)), c->d_bonds, bb, hipMemcpyDeviceToDevice, c->stream);
-    c->snap_cores = (double*)snap; c->snap_bonds = (int32_t*)((char*)snap + ((cb + 255) & ~size_t(255)));
+    double* sc = (double*)snap; int32_t* sb = (int32_t*)((char*)snap + ((cb + 255) & ~size_t(255)));
+    for (size_t k = 0; k < ins.size(); k++) {
+      hipMemcpyAsync(sc + (int64_t)k * c->slot_doubles, c->slot_cores(ins[k]), sizeof(double) * c->slot_doubles, hipMemcpyDeviceToDevice, c->stream);
+      hipMemcpyAsync(sb + (int64_t)k * (c->L + 1), c->slot_bonds(ins[k]), sizeof(int32_t) * (c->L + 1), hipMemcpyDeviceToDevice, c->stream);
+    }
+    c->snap_cores = sc; c->snap_bonds = sb;
     st = mpbp_stats{};
     rc = sweep_split(c, nodes, n_nodes, trunc, damp, &st);
     hipStreamSynchronize(c->stream);

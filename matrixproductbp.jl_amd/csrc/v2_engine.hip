@@ -33,11 +33,8 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
   }
   const int nchunk = (rows32_max + v2::CH - 1) / v2::CH;
   if (nchunk > lay.nchunk) return -1;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute((const void*)v2::k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2::fpanel_lds_bytes(3));
-    attr_done = true;
-  }
+  // per call: the attribute belongs to the (function, device) pair, and a process may hold contexts on several devices
+  hipFuncSetAttribute((const void*)v2::k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2::fpanel_lds_bytes(3));
   for (int jb = 0; jb < kmax_max; jb += 64) {
     const int npmax = std::min(4, (kmax_max - jb + 15) / 16);
     // register panels / one workgroup per problem for the in-block updates while the rows below the diagonal fit
@@ -440,8 +437,9 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
   HIPCHK(c, hipStreamSynchronize(st));     // the host vectors go out of scope below only after the loop, but keep it simple
   hipLaunchKernelGGL(v2::k_set_one, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SetOne*)done, P);
   for (int i = 0; i < P; i++) HIPCHK(c, hipMemsetAsync(bf[i].aux, 0, sizeof(double) * (size_t)lay.part, st));   // counters, T/S, slots
-  int* coop_err = c->d_counter + 8;
-  HIPCHK(c, hipMemsetAsync(coop_err, 0, sizeof(int), st));
+  // cooperative panels only while no launch of this context has timed out (launch_engine repeats a failed batch without them)
+  int* coop_err = c->no_coop_panel ? nullptr : c->d_counter + 8;
+  HIPCHK(c, hipMemsetAsync(c->d_counter + 8, 0, sizeof(int), st));
   const bool force_tall = [] { const char* e = getenv("MPBP_DEBUG_FORCE_TALL"); return e && e[0] == '1'; }();
   // ---- the time steps
   std::vector<QrDims> dims(P);

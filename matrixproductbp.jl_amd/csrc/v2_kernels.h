@@ -315,6 +315,9 @@ __global__ void __launch_bounds__(512) k_colsteps_coop(const QrProb* probs, AuxL
   MPBP_STEP(0) MPBP_STEP(1) MPBP_STEP(2) MPBP_STEP(3) MPBP_STEP(4) MPBP_STEP(5) MPBP_STEP(6) MPBP_STEP(7) MPBP_STEP(8)
   MPBP_STEP(9) MPBP_STEP(10) MPBP_STEP(11) MPBP_STEP(12) MPBP_STEP(13) MPBP_STEP(14) MPBP_STEP(15) MPBP_STEP(16)
 #undef MPBP_STEP
+  // an arrival counter timed out somewhere in the launch (workgroups not co-resident): the panel in registers is
+  // garbage - leave Y as it was; the host repeats the batch with one launch per column step (launch_engine)
+  if (__hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const int r = chunk * CH + tid + 512 * s;

@@ -122,7 +122,55 @@ def bondcap_glauber(T=6, Mb=30, sweeps=5, name="glauber_er8_T6_M30.npz"):
     _save_sweeps(bp, sweeps, OT.TruncBond(Mb), name, {"A": A, "params": np.array([N, T, Mb, sweeps, 0.5, 0.0, 1.0, m0, seed])})
 
 
+def hub_update(kind):
+    """ONE update (reference onebpiter!, src/recursive_bp_factor.jl:146-165) of a HIGH-DEGREE node from seeded random
+    messages at the saturated bond profile on all its in-edges - the shape class that BASELINE configs[2] / [3] create at
+    their hubs (cavity chains of 3z-2 products at the bond cap) and that whole-graph fixtures cannot reach offline:
+      glauber9  homogeneous Glauber (glauber_bp.jl:22-44), degree 9 (nstates grows to 10: sweep-2 factors of 600 columns,
+                Y_t up to 900 x 20 rows per rank index), T = 6, TruncBond(30)
+      karate17  SIS (sis_bp.jl), degree 17 = the larger hub of notebooks/karate.txt (49 products in CavityTools order),
+                T = 6, TruncBond(40)
+    The graph is the star hub + z leaves: with given in-messages the update of the hub does not see anything else.
+    Inputs are NOT stored: they are `random_message(T, q, Mb, rng)` of the product package drawn edge by edge from
+    numpy.random.default_rng(seed) (the test re-creates them); outputs: hub belief, f[hub], pair beliefs and bonds of the
+    hub's edges."""
+    import time
+    from mpbp_amd import random_message
+    z, T, Mb, seed = {"glauber9": (9, 6, 30, 11), "karate17": (17, 6, 40, 12)}[kind]
+    N = z + 1
+    A = np.zeros((N, N))
+    A[0, 1:] = A[1:, 0] = 1
+    g = O.IndexedBiDiGraph(A)
+    if kind == "glauber9":
+        m0 = -0.6
+        phi = [[np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+        w = OF.glauber_factors(A != 0, 0.5 * A, np.zeros(N), 1.0, T)
+        params = np.array([z, T, Mb, seed, 0.5, 0.0, 1.0, m0])
+    else:
+        lam, rho = 0.1, 0.05
+        phi = [[np.array([0.0, 1.0]) if (t == 0 and i == 1) else (np.array([1.0, 0.0]) if t == 0 else np.ones(2))
+                for t in range(T + 1)] for i in range(N)]
+        w = [[OF.SISFactor(lam, rho)] * (T + 1)] * N
+        params = np.array([z, T, Mb, seed, lam, rho])
+    bp = O.mpbp(g, w, [2] * N, T, phi=phi)
+    rng = np.random.default_rng(seed)
+    for (_, _, e) in g.inedges(0):
+        bp.mu[e] = OT.TensorTrain(random_message(T, 2, Mb, rng))
+    t0 = time.time()
+    O.onebpiter(bp, 0, OT.TruncBond(Mb))
+    print(kind, f"hub update {time.time() - t0:.1f} s", flush=True)
+    pb, lz = O.pair_beliefs(bp)
+    hub_edges = [e for (_, _, e) in g.inedges(0)] + [e for (_, _, e) in g.outedges(0)]
+    np.savez_compressed(os.path.join(HERE, f"hub_{kind}.npz"), params=params, belief=np.array(O.beliefs(bp)[0]), f=bp.f[0],
+                        hub_edges=np.array(hub_edges), pair_beliefs=np.array([pb[e] for e in hub_edges]),
+                        out_bonds=np.array([bp.mu[e].bonds for (_, _, e) in g.outedges(0)]))
+
+
 if __name__ == "__main__":
+    if "--hub" in sys.argv:
+        # OPENBLAS_NUM_THREADS=6 python tests/golden/make_golden.py --hub glauber9|karate17      (minutes each)
+        hub_update(sys.argv[sys.argv.index("--hub") + 1])
+        sys.exit(0)
     if "--bondcap" in sys.argv:
         # fixtures at the bond caps of BASELINE configs[2..4] (reduced N / T); minutes to tens of minutes each:
         #   OPENBLAS_NUM_THREADS=4 python tests/golden/make_golden.py --bondcap glauber|karate|infinite

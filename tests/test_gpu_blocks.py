@@ -121,10 +121,11 @@ def test_qr_batched_shapes(force_tall):
                 assert np.abs(G1 - G2).max() <= 1e-12 * max(np.abs(G2).max(), 1e-300), (r, c, variant, p)
 
 
-@pytest.mark.parametrize("rows,cols", [(2100, 96), (4500, 160), (6400, 400), (3000, 900)])
+@pytest.mark.parametrize("rows,cols", [(2100, 96), (4500, 160), (6400, 400), (3000, 900), (23400, 900), (21600, 900)])
 def test_qr_batched_tall(rows, cols):
     """Rows beyond one workgroup's register panel (BASELINE configs[2..4] shapes, reduced): column-step panels over
-    several row chunks, multi-chunk block-reflector updates."""
+    several row chunks, multi-chunk block-reflector updates.  23400 x 900 and 21600 x 900 are the full-size Y_t of the
+    degree-12 / degree-11 hubs of configs[2] (900 (z+1) 2 rows)."""
     rng = np.random.default_rng(22)
     A = rng.standard_normal((2, rows, cols)) * np.logspace(0, -12, cols)[None, None, :]
     R, _ = _qr_batched(A, 0)

@@ -126,6 +126,73 @@ def test_batched_gauge_sweep_matches_oracle(mode, monkeypatch):
     assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
 
 
+def _fnodes(bp):
+    import ctypes as C
+    f = np.zeros(bp.g.nv())
+    bp._L.mpbp_free_energy(bp._h, f.ctypes.data_as(C.POINTER(C.c_double)))
+    return f
+
+
+def test_split_sweep_equals_one_pass_and_oracle(monkeypatch):
+    """mpbp_sweep splits a node list whose work trains do not fit the device and lets the halves read a snapshot of the
+    in-edges (include/mpbp_hip.h: "results are those of one pass").  MPBP_DEBUG_SPLIT_NODES=2 forces the split (recursively,
+    down to pairs of nodes) on a loopy graph with damping (which reads the LIVE slab while prep reads the snapshot),
+    TruncBondMax (maxerr merged over the parts) and the n_compress count: identical to the unsplit call, equal to the oracle."""
+    N, T, Mb, damp = 10, 6, 6, 0.3
+    lam, rho, gam = 0.15, 0.1, 0.2
+    A, phi = _loopy(N, T, lam, rho, gam)
+    res = {}
+    for mode in ("one", "split"):
+        if mode == "split":
+            monkeypatch.setenv("MPBP_DEBUG_SPLIT_NODES", "2")
+        bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+        tr = M.TruncBondMax(Mb)
+        out = []
+        for s in range(3):
+            M.iterate(bp, maxiter=1, svd_trunc=tr, tol=0.0, damp=damp)
+            st = bp.last_stats
+            out.append((_flat(M.beliefs(bp)), _fnodes(bp), int(st.n_compress), float(st.maxerr)))
+        res[mode] = (out, bp.bonds().copy(), tr.maxerr)
+    monkeypatch.delenv("MPBP_DEBUG_SPLIT_NODES")
+    for (b1, f1, n1, e1), (b2, f2, n2, e2) in zip(res["one"][0], res["split"][0]):
+        assert _rel(b1, b2) < 1e-12 and np.allclose(f1, f2, rtol=1e-11, atol=1e-12)
+        assert n1 == n2 and abs(e1 - e2) <= 1e-12 * max(e1, 1e-300)
+    assert np.array_equal(res["one"][1], res["split"][1])
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    otr = OT.TruncBondMax(Mb)
+    for s in range(3):
+        O.iterate(obp, maxiter=1, svd_trunc=otr, tol=0.0, shuffle_nodes=False, jacobi=True, damp=damp)
+        assert _rel(res["split"][0][s][0], _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+    assert abs(res["split"][2] - otr.maxerr) < 1e-6 * max(otr.maxerr, 1e-12)
+
+
+def test_cooperative_panel_timeout_is_recovered(monkeypatch):
+    """The cooperative column-step kernel of the batched gauge sweep waits for its sibling workgroups inside one launch; if
+    they are not co-resident an arrival counter times out, the kernel leaves Y untouched and raises a flag.  launch_engine
+    then repeats the batch with one launch per column step - nothing has been committed to the message slab yet - and the
+    context stays in that mode.  MPBP_DEBUG_COOP_FAIL_ONCE injects the time-out on the first attempt: same results and
+    counters as a clean run, no error."""
+    monkeypatch.setenv("MPBP_GAUGE", "grid")
+    monkeypatch.setenv("MPBP_DEBUG_NO_SMALL", "1")
+    monkeypatch.setenv("MPBP_DEBUG_FORCE_TALL", "1")
+    N, T, Mb = 8, 6, 6
+    lam, rho, gam = 0.15, 0.1, 0.2
+    A, phi = _loopy(N, T, lam, rho, gam)
+    res = []
+    for inject in (False, True):
+        if inject:
+            monkeypatch.setenv("MPBP_DEBUG_COOP_FAIL_ONCE", "1")
+        bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+        out = []
+        for s in range(2):
+            M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0)
+            out.append((_flat(M.beliefs(bp)), int(bp.last_stats.n_compress)))
+        res.append(out)
+    monkeypatch.delenv("MPBP_DEBUG_COOP_FAIL_ONCE")
+    for (b1, n1), (b2, n2) in zip(*res):
+        assert _rel(b1, b2) < 1e-12 and n1 == n2
+
+
 def test_glauber_small_tree_gpu():
     """reference test/glauber_small_tree.jl:3-72 structure (star of 4 + isolated node, T=2,
     TruncBondThresh(10)); HomogeneousGlauberFactor with growing nstates = l+1."""
