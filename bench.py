@@ -156,6 +156,77 @@ def cpu_baseline(node_msgs, lam, rho, gam, T, Mb, E_per_sweep, n_heavy=64):
                        f"= {t_node:.1f} s/core")}
 
 
+def _cpu_short_op(args):
+    """Seconds of the reference-algorithm `op` (Kronecker + compress!, LAPACK gesdd sweeps) on two random trains of Lc and
+    of Lc + 1 cores whose bonds all sit at the cap Mb - the steady-state time steps of a saturated chain, without the chain.
+    Returns (t(Lc), t(Lc + 1))."""
+    kind, Mb, Lc, d1, d2, threads, seed = args
+    os.environ["OPENBLAS_NUM_THREADS"] = str(threads)
+    from oracle import mpbp as O
+    from oracle import factors as OF
+    from oracle.tensor_trains import TensorTrain, TruncBond
+    rng = np.random.default_rng(seed)
+    w = OF.HomogeneousGlauberFactor(0.5, 0.0) if kind == "glauber" else OF.SISFactor(0.1, 0.05)
+
+    def run(L_, bond):
+        mk = lambda d: TensorTrain([rng.uniform(0.5, 1.5, size=(bond, bond, w.nstates(d), 2)) / (bond * 4) for _ in range(L_)])   # noqa: E731
+        a, b = (mk(d1), d1), (mk(d2), d2)
+        t0 = time.perf_counter()
+        O.op_kron_compress([w] * L_, a, b, L_ - 1, TruncBond(bond))
+        return time.perf_counter() - t0
+    run(Lc, min(Mb, 6))          # first-call costs (imports, BLAS start-up)
+    t_a = run(Lc, Mb)
+    if t_a < 5.0:
+        t_a = run(Lc, Mb)        # cheap enough to repeat: the first full-size run also pays the page faults of its work arrays
+    return t_a, run(Lc + 1, Mb)
+
+
+def cpu_baseline_big(config, T, Mb, deg, nstates, E_per_sweep):
+    """configs[2..4]: a whole reference-algorithm `op` at these bond caps takes minutes to hours on a CPU core, so the sample
+    is the STEADY-STATE TIME STEPS of one: the `op` on chains of Lc and Lc + 1 cores with every bond (ends included) at the cap;
+    the difference is one saturated time step (both SVD sweeps + Kronecker build + carry).  That time prices
+    SURVEY 8(d)'s reference flop count of the same step (flops.op_flops), and the resulting flop rate of the reference
+    algorithm on this host prices the whole sweep (flops.node_update_flops over the config's degrees).  configs[2], [3]:
+    one process per host core on independent operands; configs[4] has ONE message: one process, BLAS threads = cores."""
+    import multiprocessing as mp
+    from mpbp_amd import flops as F
+    cores, cores_why = _host_cores()
+    kind = "glauber" if config == 2 else "sis"
+    d1 = d2 = 2 if config == 2 else 1                   # a product from the middle of a Glauber cavity (nstates 3 x 3 -> 5)
+    par = 1 if config == 4 else cores
+    thr = cores if config == 4 else 1
+    Lc = 2
+    jobs = [(kind, Mb, Lc, d1, d2, thr, 100 + k) for k in range(par)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(par) as pool:
+        th = pool.map(_cpu_short_op, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    t_short, t_long = float(np.mean([x[0] for x in th])), float(np.mean([x[1] for x in th]))
+    t_step = max(t_long - t_short, 1e-9)
+    ny = (lambda l: l + 1) if config == 2 else (lambda l: 1 if l == 0 else 2)
+
+    def ref_flops(L_):          # SURVEY 8(d)'s count on a chain with bond-1 ends, long enough to saturate in the middle
+        b = [min(Mb, 4 ** min(t, L_ - t)) if min(t, L_ - t) < 16 else Mb for t in range(L_ + 1)]
+        return F.op_flops(b, b, b, ny(d1), ny(d2), ny(d1 + d2), 2)[1]
+    step_flops = ref_flops(61) - ref_flops(60)                     # one saturated time step
+    rate = step_flops / t_step                                      # reference-algorithm flop/s of one process
+    L = T + 1
+    prof = [min(Mb, 4 ** min(t, L - t)) if min(t, L - t) < 16 else Mb for t in range(L + 1)]
+    tot = 0.0
+    for z in sorted(set(int(d) for d in deg)):
+        if z > 0:
+            tot += F.node_update_flops(prof, z, 2, ny)["reference_total"] * int(np.sum(np.asarray(deg) == z))
+    s_per_sweep = tot / (rate * par)
+    return {"value": E_per_sweep / s_per_sweep, "unit": "edge-updates/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "cores_from": cores_why, "s_per_sweep": s_per_sweep, "sample_wall_s": wall,
+            "reference_flops_per_sweep": tot, "reference_flop_rate_per_process": rate, "s_per_saturated_time_step": t_step,
+            "sample": (f"numpy oracle (LAPACK gesdd): reference-algorithm `op` at bond cap {Mb} ({kind}, nstates {ny(d1)} x {ny(d2)} -> "
+                       f"{ny(d1 + d2)}) on chains of {Lc} and {Lc + 1} cores with every bond at the cap, {par} process(es) x {thr} BLAS "
+                       f"thread(s) ({cores_why}): {t_short:.1f} s and {t_long:.1f} s -> {t_step:.1f} s per saturated time step = "
+                       f"{rate / 1e9:.1f} Gflop/s of SURVEY 8(d)'s count per process; the sweep = {tot / 1e12:.1f} Tflop of that count "
+                       f"(flops.node_update_flops over the config's degrees, T = {T}) -> {s_per_sweep:.0f} s per sweep")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +264,10 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     ndev = torch.cuda.device_count()
+    if world > max(ndev, 1):
+        # rehearsal with several ranks on one GPU: the cooperative panel kernel of the batched gauge sweep assumes that its
+        # workgroups are co-resident, i.e. that the process owns the device (include/mpbp_hip.h) - use the per-column launches
+        os.environ["MPBP_DEBUG_NO_COOP_PANEL"] = "1"
     local = local % max(ndev, 1)          # rehearsal: several ranks may share one GPU (gloo backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -245,13 +320,19 @@ def main():
         nshard = world if shardable else 1
         if world == 1 and args.shard_of > 1 and shardable:
             nshard = args.shard_of
-        cost = D.node_costs(ptr, 2, Mb, T, nstates=nstates)
+        # shards are cut by predicted time: executed flops at the measured rate + the part of a hub's dependency chain that
+        # runs alone on the chip (dist.node_times)
+        work_s, tail_s = D.node_times(ptr, 2, Mb, T, nstates=nstates)
+        cost = work_s + tail_s
         if shardable and world > 1:
             slot, S, shards = D.slot_map(ptr, oute, E, world, cost)
             nslots = world * S
         else:
             slot, S, nslots = np.arange(E, dtype=np.int32), E, E
             shards = D.shard_nodes(ptr, nshard, cost) if nshard > 1 else [(0, N)]
+        if shardable and (world > 1 or nshard > 1):
+            # fails here, before any allocation, if a rank cannot hold slab + snapshot + its largest node (dist.memory_plan)
+            D.memory_plan(ptr, 2, Mb, T, shards, nstates=nstates, hbm_bytes=float(torch.cuda.get_device_properties(dev).total_memory))
         slot_doubles = (T + 1) * Mb * Mb * 4
         cores_t = torch.zeros(nslots, slot_doubles, dtype=torch.float64, device=dev)
         bonds_t = torch.zeros(nslots, T + 2, dtype=torch.int32, device=dev)
@@ -363,7 +444,7 @@ def main():
         # cannot run the profiler on itself) - quoted, not measured in this run, and only for the configuration they
         # were taken on
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_eng_kernel.json")
             if world == 1 and args.config == 1 and (N, T, Mb) == (1024, 50, 20) and os.path.exists(pmc):
                 with open(pmc) as fh:
@@ -415,6 +496,9 @@ def main():
                 node_msgs.append([msgs[e] for e in e_in])
             out["cpu_baseline"] = cpu_baseline(node_msgs, lam, rho, gam, T, Mb, E, n_heavy=args.cpu_sample)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_big(args.config, T, Mb, deg, nstates, E)
+            out["speedup_vs_cpu_baseline"] = (E * args.steps / dt) / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -26,6 +26,81 @@ def node_costs(nbr_ptr, q, max_bond, T, nstates=None):
     return np.array([by_deg[int(d)] for d in deg])
 
 
+# Measured rates behind `node_times` (profiles/r02_config2_shard.json, r02_config3_*.log, r02_bench.json; MI355X):
+#   RATE_WG       executed flop rate of the workgroup engine at configs[1]-sized batches
+#   RATE_GRID     executed flop rate of the batched gauge sweep when many problems share a launch (configs[2] levels)
+#   PANEL_LATENCY wall time of one 16-column panel of ONE problem that has the chip to itself (launch sequence of the
+#                 batched QR + the truncating step): the degree-12 node of the configs[2] shard takes 92 s for 34
+#                 dependent products of T = 100 steps with 900 columns -> 92 / (34 * 100 * 57) s
+RATE_WG = 20e12
+RATE_GRID = 12e12
+PANEL_LATENCY = 92.0 / (34 * 100 * 57)
+
+
+def node_times(nbr_ptr, q, max_bond, T, nstates=None, grid=None):
+    """Predicted seconds of one node update: (work, tail).
+    `work` = executed flops / measured rate: it shares its launches with the other nodes of the rank.
+    `tail` = the part of the node's dependency chain that NOTHING shares: a node's 3z-2 cavity products (CavityTools order,
+    reference src/recursive_bp_factor.jl:140) run level by level; the levels up to the depth of a typical node (median
+    degree) are filled with many problems, the deeper ones hold this node's problem alone, and a single problem on the chip
+    advances at the latency of its launch sequence (PANEL_LATENCY per 16-column panel and time step), not at the flop rate.
+    Measured on the configs[2] shard: 299 s = the throughput part + the 92 s chain of its one degree-12 node.
+    The two ADD (launches on one stream are serial), so a rank's predicted time is sum(work + tail).
+    `grid`: whether the batched gauge sweep is taken (default: the library's rule, Y_t rows > 2048)."""
+    nbr_ptr = np.asarray(nbr_ptr, dtype=np.int64)
+    deg = np.diff(nbr_ptr)
+    ny = (lambda l: 1 if l == 0 else 2) if nstates is None else nstates
+    flops = node_costs(nbr_ptr, q, max_bond, T, nstates)
+    cols = min(max_bond, (q * q) ** min((T + 1) // 2, 32)) ** 2
+    zmed = int(np.median(deg[deg > 0])) if (deg > 0).any() else 0
+    d0 = max(3 * zmed - 2, 0)
+    work = np.zeros(len(deg))
+    tail = np.zeros(len(deg))
+    for i, z in enumerate(deg):
+        z = int(z)
+        if z == 0:
+            continue
+        rows = cols * ny(z) * q
+        g = (rows > 2048) if grid is None else grid
+        work[i] = flops[i] / (RATE_GRID if g else RATE_WG)
+        if g:
+            tail[i] = max(3 * z - 2 - d0, 0) * T * ((cols + 15) // 16) * PANEL_LATENCY
+    return work, tail
+
+
+def memory_plan(nbr_ptr, q, max_bond, T, shards, nstates=None, hbm_bytes=288e9, frac=0.85):
+    """Bytes every rank must be able to hold at once, checked BEFORE anything is allocated (raises MemoryError):
+      slab      all E message slots + bond tables (every rank keeps all messages: the all-gather restores them)
+      snapshot  the in-edge slots of the rank's nodes (a split Jacobi sweep reads them from a copy, mpbp_sweep)
+      node      the work trains of the rank's most expensive node (3z-2 cavity trains [b, b, nstates, q] + 2z embeddings):
+                the list of a sweep is split until a pass fits, but one node is the floor
+      gauge     the batched gauge sweep's buffers of that node's largest product (Y, Z, E, the packed Lf stack)
+    Everything else (arena beyond one node, batch size of the gauge sweep) adapts to what is free.  Returns a list of dicts."""
+    nbr_ptr = np.asarray(nbr_ptr, dtype=np.int64)
+    deg = np.diff(nbr_ptr)
+    E = int(nbr_ptr[-1])
+    L = T + 1
+    ny = (lambda l: 1 if l == 0 else 2) if nstates is None else nstates
+    slot = 8 * L * max_bond * max_bond * q * q + 4 * (L + 1)
+    out = []
+    for r, (lo, hi) in enumerate(shards):
+        zmax = int(deg[lo:hi].max()) if hi > lo else 0
+        n_in = int(nbr_ptr[hi] - nbr_ptr[lo])
+        b2 = max_bond * max_bond
+        node = 8 * L * ((3 * zmax - 2) * b2 * ny(zmax) * q + 2 * zmax * (q * max_bond) ** 2 * q * q) if zmax else 0
+        rows = b2 * ny(zmax) * q
+        gauge = 8 * (2 * rows * (b2 + 32) + (T * b2 * min(rows, b2))) if zmax else 0
+        need = E * slot + n_in * slot + node + gauge
+        plan = {"rank": r, "slab": E * slot, "snapshot": n_in * slot, "node": node, "gauge": gauge, "total": need,
+                "limit": frac * hbm_bytes}
+        if need > frac * hbm_bytes:
+            raise MemoryError(f"rank {r}: {need / 1e9:.1f} GB needed (slab {E * slot / 1e9:.1f}, snapshot "
+                              f"{n_in * slot / 1e9:.1f}, largest node {node / 1e9:.1f}, gauge sweep {gauge / 1e9:.1f}) "
+                              f"> {frac:.2f} x {hbm_bytes / 1e9:.0f} GB")
+        out.append(plan)
+    return out
+
+
 def shard_nodes(nbr_ptr, world, cost=None):
     """Contiguous node blocks of (nearly) equal total cost.  ``cost``: per-node weights (``node_costs``); default =
     out-edge counts (exact for regular graphs).  Returns list of (lo, hi)."""
@@ -45,10 +120,11 @@ def shard_nodes(nbr_ptr, world, cost=None):
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
 
 
-def slot_map(nbr_ptr, out_edge, n_edges, world, cost=None):
+def slot_map(nbr_ptr, out_edge, n_edges, world, cost=None, shards=None):
     """slot_of_edge[e]: rank-major, padded.  Edge e is owned by the rank that owns its source node
-    (= the node that has e among its out-edges).  Returns (slot_of_edge, slots_per_rank, shards)."""
-    shards = shard_nodes(nbr_ptr, world, cost)
+    (= the node that has e among its out-edges).  `shards`: node blocks to use (e.g. `shard_nodes_by_time`), default
+    `shard_nodes(nbr_ptr, world, cost)`.  Returns (slot_of_edge, slots_per_rank, shards)."""
+    shards = shard_nodes(nbr_ptr, world, cost) if shards is None else shards
     nbr_ptr = np.asarray(nbr_ptr)
     out_edge = np.asarray(out_edge)
     owner_edges = []

@@ -325,3 +325,60 @@ def test_device_algorithm_equals_reference_compress_with_binding_truncation():
                 x = [(int(rng.integers(ny)), int(rng.integers(2))) for _ in range(T + 1)]
                 ra, rb = evaluate(ref, x), evaluate(dev, x)
                 assert abs(ra - rb) <= 1e-11 * max(abs(ra), 1e-300) + 1e-14
+
+
+# ------------------------------------------------------------------------------------------ chains periodic in time
+def test_periodic_oracle_mpem2_preserves_the_function():
+    """reference test/mpems.jl:55-65: evaluate(mpem2(B)) == evaluate(B) for a random PeriodicMPEM3 (src/mpems.jl:96-155)."""
+    import itertools
+    from oracle import periodic as OP
+    rng = np.random.default_rng(5)
+    L, q, d = 3, 2, 3
+    B = OP.PeriodicMPEM3([rng.random((d, d, q, q, q)) for _ in range(L)], logz=0.3)
+    C = OP.mpem2(B)
+    for x in itertools.product(itertools.product(range(q), range(q)), repeat=L):
+        assert abs(OP.evaluate(C, [tuple(v) for v in x]) - OP.evaluate_mpem3(B, [tuple(v) for v in x])) < 1e-12
+
+
+def _periodic_tree_model():
+    from oracle import factors as OF, mpbp as O
+    T = 2
+    J = np.array([[0, 1, 0, 0, 0], [1, 0, 1, 1, 0], [0, 1, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 0, 0, 0]], float)
+    N = 5
+    rng = np.random.default_rng(111)
+    h = rng.standard_normal(N)
+    g = O.IndexedBiDiGraph(J != 0)
+    psi = [[np.ones((2, 2)) for _ in range(T + 1)] for _ in range(g.E)]
+    obs = [(0, 1, 0, np.array([[0.1, 0.9], [0.3, 0.4]])), (1, 3, 1, np.array([[0.4, 0.6], [0.5, 0.9]])),
+           (1, 2, T, rng.random((2, 2)) + 0.05)]
+    for (i, j, t, m) in obs:
+        for (a, b, e) in g.edges():
+            if (a, b) == (i, j):
+                psi[e][t] = m
+            if (a, b) == (j, i):
+                psi[e][t] = m.T.copy()
+    phi = [[np.array([0.75, 0.25]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    phi[2][1] = np.array([0.0, 1.0])
+    phi[4][2] = np.array([1.0, 0.0])
+    return g, OF.glauber_factors(J != 0, J, h, 1.0, T), phi, psi, N, T
+
+
+def test_periodic_oracle_is_exact_on_the_reference_tree():
+    """reference test/periodic.jl:1-68 (5-node tree, pair + node observations, T = 2): the restated periodic path
+    (oracle/periodic.py: PeriodicMPEM3, periodic mpem2, periodic _f_bp_partial; TensorTrains' periodic sweeps as recalled)
+    with a non-binding cap equals brute-force enumeration (src/exact.jl:24-26): beliefs, Z, pair beliefs."""
+    from oracle import periodic as OP
+    from oracle import tensor_trains as OT
+    from oracle.exact import exact_marginals, exact_pair_marginals, exact_prob
+    g, w, phi, psi, N, T = _periodic_tree_model()
+    bp = OP.periodic_mpbp(g, w, [2] * N, T, phi=phi, psi=psi)
+    OP.iterate(bp, 6, OT.TruncBondThresh(64, 1e-14))
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(bp, periodic=True)
+    b = OP.beliefs(bp)
+    ex = exact_marginals(bp, p)
+    assert max(np.abs(np.array(b[i][t]) - ex[i][t]).max() for i in range(N) for t in range(T + 1)) < 1e-9
+    assert abs(np.exp(-float(np.sum(bp.f))) - Z) / Z < 1e-9
+    pb, _ = OP.pair_beliefs(bp)
+    pex = exact_pair_marginals(bp, p)
+    assert max(np.abs(np.array(pb[e][t]) - pex[e][t]).max() for e in range(g.E) for t in range(T + 1)) < 1e-9
