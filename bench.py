@@ -166,7 +166,7 @@ def _cpu_short_op(args):
     from oracle import factors as OF
     from oracle.tensor_trains import TensorTrain, TruncBond
     rng = np.random.default_rng(seed)
-    w = OF.HomogeneousGlauberFactor(0.5, 0.0) if kind == "glauber" else OF.SISFactor(0.1, 0.05)
+    w = OF.HomogeneousGlauberFactor(0.5, 0.0, 1.0) if kind == "glauber" else OF.SISFactor(0.1, 0.05)
 
     def run(L_, bond):
         mk = lambda d: TensorTrain([rng.uniform(0.5, 1.5, size=(bond, bond, w.nstates(d), 2)) / (bond * 4) for _ in range(L_)])   # noqa: E731

@@ -164,8 +164,14 @@ int mpbp_reset_messages(mpbp_ctx* ctx);
  * the one stored, as in the reference's loop (src/recursive_bp_factor.jl:154-159).
  * Blocking: returns after the context's stream has been synchronised, so the slab may be handed to a collective on
  * any stream right away (mpbp_allgather_slots, or the caller's own RCCL call).  Node lists whose work trains do not
- * fit the device are split internally; the pieces read a snapshot of the slab taken at entry, results are those of
- * one pass.
+ * fit the device are split internally; the pieces read a snapshot, taken at entry, of the in-edge slots of the listed
+ * nodes, results are those of one pass (tests/test_gpu_parity.py::test_split_sweep_equals_one_pass_and_oracle).
+ * Device ownership: the batched gauge sweep (products whose Y_t exceeds 2048 rows) factors tall panels with a
+ * cooperative kernel whose row-chunk workgroups wait for each other inside one launch; it is only launched when the grid
+ * fits 3/4 of the CUs, which guarantees co-residency IF this process is the only one computing on the device.  With
+ * other work resident (a second process, another stream of the caller) an arrival counter can time out: the kernel then
+ * leaves its panel untouched, the library repeats the batch with one launch per column step and keeps the context in
+ * that mode - slower, never wrong.  MPBP_DEBUG_NO_COOP_PANEL=1 starts in that mode (ranks that share a device).
  */
 int mpbp_sweep(mpbp_ctx* ctx, const int32_t* nodes, int32_t n_nodes, mpbp_trunc trunc, double damp,
                mpbp_stats* stats /* may be NULL */);
@@ -212,12 +218,12 @@ int mpbp_selftest_jacobi_bench(int32_t device, int32_t m, int32_t n, int32_t nbl
                                int32_t reps, double* ms_out, double* avg_sweeps);
 int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, const double* A, double* sigma,
                       double* V);
-/* nprob independent rows x cols matrices (A: [nprob][rows x cols] column-major) through the grid-level batched QR of
- * the gauge sweep (csrc/v2_kernels.h); R: [nprob][min(rows,cols) x cols]; force_tall: column-step panels always. */
 /* the multi-launch (grid-level) one-sided Jacobi of the batched truncating sweep on one m x n matrix (n <= m <= 1024):
  * column norms after convergence and the number of sweeps (-1: not converged) */
 int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps,
                               int32_t* sweeps);
+/* nprob independent rows x cols matrices (A: [nprob][rows x cols] column-major) through the grid-level batched QR of
+ * the gauge sweep (csrc/v2_kernels.h); R: [nprob][min(rows,cols) x cols]; force_tall: column-step panels always. */
 int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t cols, int32_t nprob, int32_t force_tall,
                              const double* A, double* R, double* ms_out);
 

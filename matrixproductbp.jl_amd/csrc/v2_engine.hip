@@ -20,10 +20,56 @@ inline int r32i(int x) { return (x + 31) & ~31; }
 
 struct QrDims { int rows, cols, kmax; };
 
+// ------------------------------------------------------------------------------------------------------------------
+// Look-ahead for the latency-bound case (one or two LARGE problems per launch: configs[3] hubs, configs[4]): the panel
+// factorisation of block k+1 (17 cooperative column steps + Gram + T per 16 columns, ~25 launches per 64 columns, a
+// handful of workgroups each) runs BESIDE the trailing update of block k instead of after it.  Two internal streams with
+// disjoint CU masks (hipExtStreamCreateWithCUMask): the panel chain owns LA_RESERVED CUs - so the cooperative kernel's
+// workgroups are co-resident by construction and its VALU-bound column steps do not share SIMDs with the trailing
+// update's MFMA streams (which would slow them 3x, profiles/r03_dp_pipe_probe.txt) - the trailing update the rest.
+//   stream B:  panel chain of block k   record(b)   wait(a: part 2 of block k-1)   part 1 of block k   ...block k+1
+//   stream A:  wait(b)   part 2 of block k   record(a)
+// part 1 = the next block's four panel tiles, updated in the fine-grained form of the in-block updates (quarter row
+// chunks, ~90 us; the (8 tiles x row chunk) form takes ~340 us whatever the tile count: its time is one workgroup's pass
+// over its 2048 rows), part 2 = all other tiles in the (8 tiles x row chunk) form.  Part 1 of block k needs part 2 of
+// block k-1 (which brought those columns up to block k-1); block k+1's chain writes the second copy of the per-problem
+// scratch (shift_auxlay) while part 2 of block k reads the first.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int LA_RESERVED = 64;      // CUs of the panel stream
+constexpr int LA_MAX_WGS = 24;       // look-ahead only while the batch is latency bound: row-chunk workgroups of all its problems (6400 x 1600 x 16 with 64 of them is throughput bound and loses 20 % to the reserved CUs)
+struct LookAhead {
+  hipStream_t sa = nullptr, sb = nullptr;
+  hipEvent_t e_in = nullptr, e_a[2] = {nullptr, nullptr}, e_b = nullptr, e_out_a = nullptr, e_out_b = nullptr;
+  bool ok = false, tried = false;
+};
+static LookAhead* lookahead_streams() {
+  static LookAhead la[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  LookAhead& l = la[dev];
+  if (!l.tried) {
+    l.tried = true;
+    if (getenv("MPBP_DEBUG_NO_LOOKAHEAD")) return nullptr;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return nullptr;
+    const int ncu = pr.multiProcessorCount, words = (ncu + 31) / 32;
+    if (ncu < 4 * LA_RESERVED) return nullptr;
+    std::vector<uint32_t> mb(words, 0u), ma(words, 0u);
+    for (int i = 0; i < ncu; i++) (i < LA_RESERVED ? mb : ma)[i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(&l.sa, words, ma.data()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipExtStreamCreateWithCUMask(&l.sb, words, mb.data()) != hipSuccess) { (void)hipGetLastError(); hipStreamDestroy(l.sa); return nullptr; }
+    bool ev = true;
+    for (hipEvent_t* e : {&l.e_in, &l.e_a[0], &l.e_a[1], &l.e_b, &l.e_out_a, &l.e_out_b}) ev = ev && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    l.ok = ev;
+  }
+  return l.ok ? &l : nullptr;
+}
+
 // Launch sequence of one R-only QR over a batch whose dimensions `dims` are known on the host.
 // d_probs: device array of v2::QrProb (same order as dims).  force_tall: column-step panels even when they would fit.
+// aux2: every problem's scratch holds TWO AuxLay copies (auxd doubles apart) - required for the look-ahead.
 int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims>& dims, const v2::AuxLay& lay,
-             bool force_tall, int* coop_err = nullptr, int coop_max_wgs = 128) {
+             bool force_tall, int* coop_err = nullptr, int coop_max_wgs = 128, int64_t aux2 = 0) {
   const int P = (int)dims.size();
   if (P == 0) return 0;
   int kmax_max = 0, kmax_min = 1 << 30, rows32_max = 0, cols_max = 0;
@@ -35,30 +81,30 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
   if (nchunk > lay.nchunk) return -1;
   // per call: the attribute belongs to the (function, device) pair, and a process may hold contexts on several devices
   hipFuncSetAttribute((const void*)v2::k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2::fpanel_lds_bytes(3));
-  for (int jb = 0; jb < kmax_max; jb += 64) {
-    const int npmax = std::min(4, (kmax_max - jb + 15) / 16);
-    // register panels / one workgroup per problem for the in-block updates while the rows below the diagonal fit
-    const bool tall = force_tall || rows32_max - jb > v2::CH;
+  static const bool no_coop = getenv("MPBP_DEBUG_NO_COOP_PANEL") != nullptr;
+
+  // ---- the panel chain of block jb (4 panels: in-block update, column steps, Gram, T) on stream s with scratch layout L
+  auto panel_chain = [&](hipStream_t s, const v2::AuxLay& L, int jb, int npmax, bool tall, int coop_wgs) {
     for (int p = 0; p < npmax; p++) {
       const int jp = jb + 16 * p;
       if (p > 0) {
         if (!tall) {
           switch (p) {
-            case 1: hipLaunchKernelGGL(v2::k_inblock<1>, dim3(P), dim3(512), 0, st, d_probs, lay, jb); break;
-            case 2: hipLaunchKernelGGL(v2::k_inblock<2>, dim3(P), dim3(512), 0, st, d_probs, lay, jb); break;
-            default: hipLaunchKernelGGL(v2::k_inblock<3>, dim3(P), dim3(512), 0, st, d_probs, lay, jb); break;
+            case 1: hipLaunchKernelGGL(v2::k_inblock<1>, dim3(P), dim3(512), 0, s, d_probs, L, jb); break;
+            case 2: hipLaunchKernelGGL(v2::k_inblock<2>, dim3(P), dim3(512), 0, s, d_probs, L, jb); break;
+            default: hipLaunchKernelGGL(v2::k_inblock<3>, dim3(P), dim3(512), 0, s, d_probs, L, jb); break;
           }
         } else {
           // few problems: a quarter chunk per workgroup (tw = 0, grid.x = 4); many: a chunk per workgroup (tw = 1)
           const int twi = ((int64_t)nchunk * P <= 128) ? 0 : 1;
           const dim3 g(twi == 0 ? 4 : 1, nchunk, P);
           switch (p) {
-            case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0);
-                    hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0); break;
-            case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0);
-                    hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0); break;
-            default: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0);
-                     hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 1, twi, 0); break;
+            case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0);
+                    hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0); break;
+            case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0);
+                    hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0); break;
+            default: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0);
+                     hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0); break;
           }
         }
       }
@@ -66,26 +112,86 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
         // every row-chunk workgroup resident at once: one launch with arrival counters; else one launch per column
         // (the cooperative kernel needs all the row-chunk workgroups of a problem resident together: a batch too large
         // for that goes through it in groups of problems, as long as that takes fewer launches than the 17 column steps)
-        static const bool no_coop = getenv("MPBP_DEBUG_NO_COOP_PANEL") != nullptr;
-        const int pb = (nchunk > 0) ? coop_max_wgs / nchunk : 0;          // problems per cooperative launch
+        const int pb = (nchunk > 0) ? coop_wgs / nchunk : 0;          // problems per cooperative launch
         if (coop_err && !no_coop && pb >= 1 && (P + pb - 1) / pb <= 8) {
           for (int p0 = 0; p0 < P; p0 += pb)
-            hipLaunchKernelGGL(v2::k_colsteps_coop, dim3(nchunk, std::min(pb, P - p0)), dim3(512), 0, st, d_probs + p0, lay, jp, p, coop_err);
+            hipLaunchKernelGGL(v2::k_colsteps_coop, dim3(nchunk, std::min(pb, P - p0)), dim3(512), 0, s, d_probs + p0, L, jp, p, coop_err);
         } else
           for (int jj = 0; jj <= 16; jj++)
-            hipLaunchKernelGGL(v2::k_colstep, dim3(nchunk, P), dim3(512), 0, st, d_probs, lay, jp, jj, p);
-        hipLaunchKernelGGL(v2::k_gram, dim3(nchunk * v2::GSUB, P), dim3(512), 0, st, d_probs, lay, jb, p);
-        hipLaunchKernelGGL(v2::k_build_T, dim3(P), dim3(256), 0, st, d_probs, lay, jb, p);
+            hipLaunchKernelGGL(v2::k_colstep, dim3(nchunk, P), dim3(512), 0, s, d_probs, L, jp, jj, p);
+        hipLaunchKernelGGL(v2::k_gram, dim3(nchunk * v2::GSUB, P), dim3(512), 0, s, d_probs, L, jb, p);
+        hipLaunchKernelGGL(v2::k_build_T, dim3(P), dim3(256), 0, s, d_probs, L, jb, p);
       } else {
-        hipLaunchKernelGGL(v2::k_fpanel, dim3(P), dim3(512), v2::fpanel_lds_bytes(p), st, d_probs, lay, jb, p);
+        hipLaunchKernelGGL(v2::k_fpanel, dim3(P), dim3(512), v2::fpanel_lds_bytes(p), s, d_probs, L, jb, p);
       }
     }
+  };
+  static const int coop_nt = [] { const char* e = getenv("MPBP_COOP_NT"); return e ? atoi(e) : 0; }();
+  // tiles [t0, t1) of the 4-panel trailing update in the (8 tiles x row chunk) form
+  auto trail_coop = [&](hipStream_t s, const v2::AuxLay& L, int jb, int t0, int t1) {
+    if (t1 <= t0) return;
+    const bool nt1 = coop_nt != 2;   // one tile per wave measured 8-20 % faster at every size tried (two workgroups per CU)
+    if (nt1) {
+      const dim3 gc((t1 - t0 + 7) / 8, nchunk, P);
+      hipLaunchKernelGGL(v2::k_trailW_coop<1>, gc, dim3(512), 0, s, d_probs, L, jb, t0, t1);
+      hipLaunchKernelGGL(v2::k_trailU_coop<1>, gc, dim3(512), 0, s, d_probs, L, jb, t0, t1);
+    } else {
+      const dim3 gc((t1 - t0 + 15) / 16, nchunk, P);
+      hipLaunchKernelGGL(v2::k_trailW_coop<2>, gc, dim3(512), 0, s, d_probs, L, jb, t0, t1);
+      hipLaunchKernelGGL(v2::k_trailU_coop<2>, gc, dim3(512), 0, s, d_probs, L, jb, t0, t1);
+    }
+  };
+
+  // ---- look-ahead: uniform large problems only (every block has four full panels for every problem, the cooperative
+  //      panel kernel fits the reserved CUs, the trailing matrix is wide enough to have a part 2)
+  LookAhead* la = (aux2 > 0 && coop_err && !no_coop && !getenv("MPBP_DEBUG_NO_COOP_TRAIL")) ? lookahead_streams() : nullptr;
+  const bool la_shape = la && (int64_t)nchunk * P <= LA_MAX_WGS && rows32_max > 2 * v2::CH && kmax_min == kmax_max;
+  const v2::AuxLay lay2[2] = {lay, v2::shift_auxlay(lay, aux2)};
+  bool la_on = false;
+  int la_par = 0;
+  auto la_leave = [&]() {
+    if (!la_on) return;
+    hipEventRecord(la->e_out_a, la->sa); hipEventRecord(la->e_out_b, la->sb);
+    hipStreamWaitEvent(st, la->e_out_a, 0); hipStreamWaitEvent(st, la->e_out_b, 0);
+    la_on = false;
+  };
+
+  for (int jb = 0; jb < kmax_max; jb += 64) {
+    const int npmax = std::min(4, (kmax_max - jb + 15) / 16);
+    // register panels / one workgroup per problem for the in-block updates while the rows below the diagonal fit
+    const bool tall = force_tall || rows32_max - jb > v2::CH;
+    const int ntile4 = cols_max > jb + 64 ? (cols_max - jb - 64 + 15) / 16 : 0;
+    if (la_shape && tall && npmax == 4 && kmax_min - jb >= 64 && ntile4 > 8 && rows32_max - jb > 2 * v2::CH) {
+      const bool first = !la_on;
+      if (first) {
+        hipEventRecord(la->e_in, st);
+        hipStreamWaitEvent(la->sa, la->e_in, 0); hipStreamWaitEvent(la->sb, la->e_in, 0);
+        la_on = true; la_par = 0;
+      }
+      const v2::AuxLay& L = lay2[la_par];
+      panel_chain(la->sb, L, jb, 4, true, LA_RESERVED);
+      hipEventRecord(la->e_b, la->sb);
+      // part 2 beside the next block's chain
+      hipStreamWaitEvent(la->sa, la->e_b, 0);
+      trail_coop(la->sa, L, jb, 4, ntile4);
+      hipEventRecord(la->e_a[la_par], la->sa);
+      // part 1 (the next block's panel tiles) behind part 2 of the previous block
+      if (!first) hipStreamWaitEvent(la->sb, la->e_a[la_par ^ 1], 0);
+      {
+        const dim3 g(16, nchunk, P);
+        hipLaunchKernelGGL(v2::k_trailW<4>, g, dim3(256), 0, la->sb, d_probs, L, jb, 0, 0, 0);
+        hipLaunchKernelGGL(v2::k_trailU<4>, g, dim3(256), 0, la->sb, d_probs, L, jb, 0, 0, 0);
+      }
+      la_par ^= 1;
+      continue;
+    }
+    la_leave();
+    panel_chain(st, lay, jb, npmax, tall, coop_max_wgs);
     const int c0min = jb + 16;     // a problem with one panel left starts its trailing tiles here
     const int ntile_max = cols_max > c0min ? (cols_max - c0min + 15) / 16 : 0;
     if (ntile_max > 0) {
       // Many problems: one wave per tile pair over all rows (fused, the tuned wg::qr_trail4); few: tiles x row chunks
       // over the grid in two launches.  Problems with fewer than four panels left always take the second form.
-      const int ntile4 = cols_max > jb + 64 ? (cols_max - jb - 64 + 15) / 16 : 0;
       const bool fused = npmax == 4 && ntile4 > 0 && (int64_t)P * ((ntile4 + 1) / 2) >= 1024 && !getenv("MPBP_DEBUG_NO_FUSED_TRAIL");
       static const int trail_nt = [] { const char* e = getenv("MPBP_TRAIL_NT"); return e ? atoi(e) : 2; }();
       if (fused) {
@@ -94,19 +200,7 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       }
       // few large problems: (16 tiles x row chunk) workgroups with the panels shared through LDS, two launches
       const bool coop = !fused && npmax == 4 && ntile4 > 0 && !getenv("MPBP_DEBUG_NO_COOP_TRAIL");
-      if (coop) {
-        static const int coop_nt = [] { const char* e = getenv("MPBP_COOP_NT"); return e ? atoi(e) : 0; }();
-        const bool nt1 = coop_nt != 2;   // one tile per wave measured 8-20 % faster at every size tried (two workgroups per CU)
-        if (nt1) {
-          const dim3 gc((ntile4 + 7) / 8, nchunk, P);
-          hipLaunchKernelGGL(v2::k_trailW_coop<1>, gc, dim3(512), 0, st, d_probs, lay, jb);
-          hipLaunchKernelGGL(v2::k_trailU_coop<1>, gc, dim3(512), 0, st, d_probs, lay, jb);
-        } else {
-          const dim3 gc((ntile4 + 15) / 16, nchunk, P);
-          hipLaunchKernelGGL(v2::k_trailW_coop<2>, gc, dim3(512), 0, st, d_probs, lay, jb);
-          hipLaunchKernelGGL(v2::k_trailU_coop<2>, gc, dim3(512), 0, st, d_probs, lay, jb);
-        }
-      }
+      if (coop) trail_coop(st, lay, jb, 0, ntile4);
       const int only_short = (fused || coop) ? 1 : 0;
       if ((!fused && !coop) || kmax_min - jb < 64) {
         const dim3 g((ntile_max + 3) / 4, nchunk, P);
@@ -123,6 +217,7 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       }
     }
   }
+  la_leave();
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -145,9 +240,9 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
   const size_t auxd = (size_t)v2::auxlay_doubles(nchunk, ntile);
   double *dY = nullptr, *dAux = nullptr; v2::QrProb* dP = nullptr;
   ST2CHK(hipMalloc(&dY, sizeof(double) * per * nprob));
-  ST2CHK(hipMalloc(&dAux, sizeof(double) * auxd * nprob));
+  ST2CHK(hipMalloc(&dAux, sizeof(double) * 2 * auxd * nprob));          // two scratch copies per problem: look-ahead of qr_batch
   ST2CHK(hipMalloc(&dP, sizeof(v2::QrProb) * nprob));
-  ST2CHK(hipMemset(dAux, 0, sizeof(double) * auxd * nprob));
+  ST2CHK(hipMemset(dAux, 0, sizeof(double) * 2 * auxd * nprob));
   std::vector<double> Y(per, 0.0);
   std::vector<v2::QrProb> hp(nprob);
   std::vector<QrDims> dims(nprob);
@@ -156,7 +251,7 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
     const double* Ap = A + (size_t)p * rows * cols;
     for (int j = 0; j < cols; j++) for (int i = 0; i < rows; i++) Y[i + (size_t)ld * j] = Ap[i + (size_t)rows * j];
     ST2CHK(hipMemcpy(dY + per * p, Y.data(), sizeof(double) * per, hipMemcpyHostToDevice));
-    hp[p] = v2::QrProb{dY + per * p, dAux + auxd * p, ld, rows, cols, kmax};
+    hp[p] = v2::QrProb{dY + per * p, dAux + 2 * auxd * p, ld, rows, cols, kmax};
     dims[p] = QrDims{rows, cols, kmax};
   }
   ST2CHK(hipMemcpy(dP, hp.data(), sizeof(v2::QrProb) * nprob, hipMemcpyHostToDevice));
@@ -165,7 +260,7 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
   int* dErr = nullptr;
   ST2CHK(hipMalloc(&dErr, sizeof(int)));
   ST2CHK(hipMemset(dErr, 0, sizeof(int)));
-  const int rc = qr_batch(0, dP, dims, lay, force_tall != 0, dErr);
+  const int rc = qr_batch(0, dP, dims, lay, force_tall != 0, dErr, 128, (int64_t)auxd);
   hipEventRecord(e1, 0);
   ST2CHK(hipDeviceSynchronize());
   if (rc != 0) { g_create_error = "qr_batch launch failed"; return MPBP_EHIP; }
@@ -343,7 +438,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     // aux is sized by the batch maxima: recompute the total when they grow
     size_t tot = 0;
     for (int k = 0; k <= i; k++)
-      tot += al(plan[k].y_doubles) + al(plan[k].z_doubles) + al(plan[k].e_doubles) + al(plan[k].lf_doubles) + al(v2::auxlay_doubles(nc, nt)) +
+      tot += al(plan[k].y_doubles) + al(plan[k].z_doubles) + al(plan[k].e_doubles) + al(plan[k].lf_doubles) + al(2 * v2::auxlay_doubles(nc, nt)) +
              (((size_t)(L + 1) * 12 + 255) & ~size_t(255)) +
              (trunc2 ? 2 * al(plan[k].c_doubles) + al(plan[k].t1_doubles) + al(plan[k].nt_doubles) + al(plan[k].mt_doubles) + al(plan[k].ja_doubles) + al(plan[k].u_doubles) + 512 : 0);
     const size_t desc = (size_t)(i + 1) * L * (sizeof(v2::QrProb) * 2 + sizeof(v2::GemmDesc) * (4 + 2 * c->q) + sizeof(v2::EDesc) + sizeof(v2::LfDesc) + sizeof(v2::ScaleDesc) + sizeof(v2::SvdDesc)) + 65536;
@@ -364,7 +459,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
   std::vector<Bufs> bf(P);
   for (int i = 0; i < P; i++) {
     bf[i].Y = (double*)take(al(plan[i].y_doubles)); bf[i].Z = (double*)take(al(plan[i].z_doubles));
-    bf[i].E = (double*)take(al(plan[i].e_doubles)); bf[i].aux = (double*)take(al(auxd)); bf[i].lf = (double*)take(al(plan[i].lf_doubles));
+    bf[i].E = (double*)take(al(plan[i].e_doubles)); bf[i].aux = (double*)take(al(2 * auxd));          /* two scratch copies: look-ahead of qr_batch */ bf[i].lf = (double*)take(al(plan[i].lf_doubles));
     char* tb = take((size_t)(L + 1) * 12);
     bf[i].lfoff = (int64_t*)tb; bf[i].rdim = (int32_t*)(tb + (size_t)(L + 1) * 8);
     if (trunc2) {
@@ -436,7 +531,10 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     HIPCHK(c, hipMemcpyAsync(bf[i].lfoff, htab.data() + (size_t)i * (L + 1) * 12, (size_t)(L + 1) * 12, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));     // the host vectors go out of scope below only after the loop, but keep it simple
   hipLaunchKernelGGL(v2::k_set_one, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SetOne*)done, P);
-  for (int i = 0; i < P; i++) HIPCHK(c, hipMemsetAsync(bf[i].aux, 0, sizeof(double) * (size_t)lay.part, st));   // counters, T/S, slots
+  for (int i = 0; i < P; i++) {                                                       // counters, T/S, slots of both scratch copies
+    HIPCHK(c, hipMemsetAsync(bf[i].aux, 0, sizeof(double) * (size_t)lay.part, st));
+    HIPCHK(c, hipMemsetAsync(bf[i].aux + auxd, 0, sizeof(double) * (size_t)lay.part, st));
+  }
   // cooperative panels only while no launch of this context has timed out (launch_engine repeats a failed batch without them)
   int* coop_err = c->no_coop_panel ? nullptr : c->d_counter + 8;
   HIPCHK(c, hipMemsetAsync(c->d_counter + 8, 0, sizeof(int), st));
@@ -459,7 +557,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN1 + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dg1 + o));
     hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
     hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN2 + 127) / 128), P * q), dim3(512), 0, st, (const v2::GemmDesc*)(dg2 + o * q));
-    if (qr_batch(st, dq + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (qr_batch(st, dq + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4, auxd) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
     const int gw = std::min(256, std::max(1, (colsm + 3) / 4));
     hipLaunchKernelGGL(v2::k_maxabs, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
     hipLaunchKernelGGL(v2::k_lf_write, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), (const v2::LfDesc*)(dl + o), lay);
@@ -593,7 +691,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq2 + o), lay);
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNm + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dmt + o));
       tm.end(1); tm.begin();
-      if (qr_batch(st, dq2 + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
+      if (qr_batch(st, dq2 + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4, auxd) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
       // the SVD of the triangular factor: inside one workgroup, or - factors of several hundred columns - as rounds of
       // rotations over the grid (659 launches per sweep at 660 columns: 20+ workgroups rotate at once, a one-workgroup
       // tournament of that size takes 0.3 s per time step)

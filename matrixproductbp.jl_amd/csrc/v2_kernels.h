@@ -54,6 +54,12 @@ __host__ __device__ inline AuxLay make_auxlay(int nchunk, int ntile) {
   (void)o;
   return a;
 }
+// the same layout `off` doubles further on (second buffer of the look-ahead: block k+1's panel factorisation writes its
+// T / S / partial products while block k's trailing update still reads its own)
+__host__ __device__ inline AuxLay shift_auxlay(AuxLay a, int64_t off) {
+  a.T += off; a.S += off; a.tau += off; a.piv += off; a.mx += off; a.bar += off; a.part += off; a.gram += off; a.w0 += off;
+  return a;
+}
 __host__ __device__ inline int64_t auxlay_doubles(int nchunk, int ntile) {
   return 4 * 256 + 6 * 256 + 64 + 256 + 16 + 16 + (int64_t)nchunk * 256 + (int64_t)nchunk * GSUB * 1024 + (int64_t)ntile * nchunk * 4096;
 }
@@ -638,7 +644,9 @@ __global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay,
   // on the chip; the four waves' products are summed through LDS into the same slot layout (chunk * 4 + quarter)
   const bool fine = tw == 0;
   const int rw = fine ? 4 : 4 / tw;
-  const int tile = fine ? 0 : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)blockIdx.x : wave / tw;
+  // fine form: grid.x = 4 * tiles (the in-block update has one tile; the look-ahead of qr_batch updates the next block's
+  // four panel tiles this way, inblock = 0)
+  const int tile = fine ? (int)(blockIdx.x >> 2) : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)(blockIdx.x & 3) : wave / tw;
   if (tile >= G.ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
@@ -712,7 +720,7 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
   __syncthreads();
   const bool fine = tw == 0;                               // see k_trailW
   const int rw = fine ? 4 : 4 / tw;
-  const int tile = fine ? 0 : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)blockIdx.x : wave / tw;
+  const int tile = fine ? (int)(blockIdx.x >> 2) : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)(blockIdx.x & 3) : wave / tw;
   if (tile >= G.ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
@@ -851,12 +859,14 @@ struct CoopStage {
 };
 
 template <int NT>
-__global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailW_coop(const QrProb* probs, AuxLay lay, int jb) {
+__global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailW_coop(const QrProb* probs, AuxLay lay, int jb, int t0, int t1) {
+  // tiles [t0, t1) of the trailing matrix (counted from column jb + 64): the look-ahead of qr_batch updates the next
+  // blocks' panel columns first and the rest beside the next panel factorisation
   const QrProb P = probs[blockIdx.z];
   if (P.kmax - jb < 64) return;
   const int c0 = jb + 64;
-  const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
-  if (blockIdx.x * 8 * NT >= ntile) return;
+  const int ntile = min(t1, (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0);
+  if (t0 + blockIdx.x * 8 * NT >= ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
   const int s0 = max(chunk * CH, jb) >> 5, s1 = min((chunk + 1) * CH, rows32) >> 5;     // stages of this chunk
@@ -867,7 +877,7 @@ __global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailW_coop(const QrPr
   const long ld = P.ld;
   __shared__ double vs_[2 * QR_VS_STAGE];
   ldbl* Vs = (ldbl*)vs_;
-  const int tile = blockIdx.x * 8 * NT + NT * wave;
+  const int tile = t0 + blockIdx.x * 8 * NT + NT * wave;
   const int nt = max(0, min(NT, ntile - tile));
   const int cq0 = c0 + 16 * ((nt >= 1) ? tile : 0), cq1 = (nt >= 2) ? cq0 + 16 : cq0;
   d4 w0[4][NT];
@@ -929,12 +939,12 @@ __global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailW_coop(const QrPr
 }
 
 template <int NT>
-__global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailU_coop(const QrProb* probs, AuxLay lay, int jb) {
+__global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailU_coop(const QrProb* probs, AuxLay lay, int jb, int t0, int t1) {
   const QrProb P = probs[blockIdx.z];
   if (P.kmax - jb < 64) return;
   const int c0 = jb + 64;
-  const int ntile = (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0;
-  if (blockIdx.x * 8 * NT >= ntile) return;
+  const int ntile = min(t1, (P.cols > c0) ? (P.cols - c0 + 15) >> 4 : 0);
+  if (t0 + blockIdx.x * 8 * NT >= ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
   const int s0 = max(chunk * CH, jb) >> 5, s1 = min((chunk + 1) * CH, rows32) >> 5;
@@ -950,7 +960,7 @@ __global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailU_coop(const QrPr
   ldbl* Vs = Sq + 6 * 256;
   for (int i = tid; i < 4 * 256; i += 512) Tq[i] = aux[lay.T + i];
   for (int i = tid; i < 6 * 256; i += 512) Sq[i] = aux[lay.S + i];
-  const int tile = blockIdx.x * 8 * NT + NT * wave;
+  const int tile = t0 + blockIdx.x * 8 * NT + NT * wave;
   const int nt = max(0, min(NT, ntile - tile));
   const int tq0 = (nt >= 1) ? tile : 0, tq1 = (nt >= 2) ? tile + 1 : tq0;
   const int cq0 = c0 + 16 * tq0, cq1 = c0 + 16 * tq1;

@@ -493,6 +493,16 @@ def twovar_marginals(cores, maxdist=None):
     return out
 
 
+def _abi_maxdist(maxdist):
+    """mpbp_twovar_marginals takes maxdist <= 0 as "all distances"; here None means all, and 0 or less means NO pair
+    (TensorTrains' twovar_marginals(; maxdist) loops u in t+1 : min(L, t + maxdist)): returns -1 for "skip the call"."""
+    if maxdist is None:
+        return 0
+    if int(maxdist) <= 0:
+        return -1
+    return int(maxdist)
+
+
 def beliefs_tu(bp: MPBP, sites=None, maxdist=None):
     """`beliefs_tu` (src/mpbp.jl:239-243): two-time marginals `out[i][t][u][x_t, x_u]` (t < u <= t + maxdist, else
     None) of the listed nodes, computed on the device from the belief trains (mpbp_twovar_marginals)."""
@@ -500,8 +510,9 @@ def beliefs_tu(bp: MPBP, sites=None, maxdist=None):
     L, q = bp.T + 1, bp.q
     nodes = np.ascontiguousarray(sites, dtype=np.int32)
     buf = np.zeros(len(sites) * L * L * q * q)
-    md = 0 if maxdist is None else int(maxdist)
-    _lib.check(bp._L.mpbp_twovar_marginals(bp._h, _ip(nodes), int(nodes.size), md, _dp(buf)), bp._h)
+    md = _abi_maxdist(maxdist)
+    if md >= 0:           # maxdist = 0: no pair at all - nothing to compute (the ABI's 0 means "all distances")
+        _lib.check(bp._L.mpbp_twovar_marginals(bp._h, _ip(nodes), int(nodes.size), md, _dp(buf)), bp._h)
     arr = buf.reshape((len(sites), L, L, q, q))           # [k][t][u][y][x] in memory order x fastest
     md = L if maxdist is None else int(maxdist)
     return [[[arr[k, t, u].T.copy() if t < u <= t + md else None for u in range(L)] for t in range(L)]
@@ -515,8 +526,9 @@ def autocorrelations(f, bp: MPBP, sites=None, maxdist=None):
     L, q = bp.T + 1, bp.q
     nodes = np.ascontiguousarray(sites, dtype=np.int32)
     buf = np.zeros(len(sites) * L * L * q * q)
-    md = 0 if maxdist is None else int(maxdist)
-    _lib.check(bp._L.mpbp_twovar_marginals(bp._h, _ip(nodes), int(nodes.size), md, _dp(buf)), bp._h)
+    md = _abi_maxdist(maxdist)
+    if md >= 0:           # maxdist = 0: no pair at all (zeros), the same meaning as in beliefs_tu
+        _lib.check(bp._L.mpbp_twovar_marginals(bp._h, _ip(nodes), int(nodes.size), md, _dp(buf)), bp._h)
     arr = buf.reshape((len(sites), L, L, q, q))
     out = []
     for k, i in enumerate(sites):

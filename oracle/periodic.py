@@ -7,22 +7,75 @@ In tree (restated line by line):
   periodic_mpbp                       src/mpbp.jl:399-409
   onebpiter! / set_msg! / pair_belief are the generic ones (src/recursive_bp_factor.jl:146-179, src/bp_core.jl:95-109)
 NOT in tree (TensorTrains.jl 0.12, `PeriodicTensorTrain`): compress!, orthogonalize_right!/left!, normalize!,
-  normalization, marginals, _compose.  [R] = the author's recollection: the sweeps are the open-chain ones run on a train
-  whose first left bond and last right bond are equal instead of 1 (the trace closure plays no role in the truncation);
-  normalisation and marginals close the product with a trace.  The lossless regime of all of these is pinned by
-  enumeration (tests/test_oracle.py::test_periodic_oracle_*); the TRUNCATING behaviour of compress! on a periodic train
-  is what cannot be pinned from the reference tree - see DESIGN.md section 7.
+  normalization, marginals, _compose.  [R] = restated by analogy, NOT from source: the sweeps are taken to be CYCLIC like
+  the in-tree periodic mpem2 (src/mpems.jl:134-152: every site is split by an SVD, the carry of the last one is folded
+  into the FIRST core), so that the boundary bond is truncated like every other one - an open-chain sweep over a train
+  with a boundary bond would never truncate it, and the bonds of the reference's own loopy periodic test
+  (test/periodic.jl:87, TruncBond(10)) would grow without bound (measured here: 2, 8, 80, ... per sweep).  Normalisation and
+  marginals close the product with a trace.  The lossless regime of all of these is pinned by enumeration
+  (tests/test_oracle.py::test_periodic_oracle_*); which subspaces a TRUNCATING sweep keeps on a ring is what cannot be
+  pinned from the reference tree - the blocker is `TensorTrains.orthogonalize_right!/left!(::PeriodicTensorTrain)`
+  (call sites src/recursive_bp_factor.jl:127,156,174) - see DESIGN.md section 7.
 Only tests/ may import this module."""
 from __future__ import annotations
 
 import numpy as np
 
 from . import mpbp as O
-from .tensor_trains import TensorTrain, _reshape1, _reshapeas, compress, normalize_eachmatrix
+from .tensor_trains import TensorTrain, TruncThresh, _rescale, _reshape1, _reshapeas, normalize_eachmatrix
 
 
 def _summed(a):
     return _reshape1(a).sum(axis=2)
+
+
+def orthogonalize_right(C, svd_trunc):
+    """[R] cyclic right sweep: t = L..1, M[m,(n,x)] = core t, SVD, core t <- V^T, carry U diag(lambda) into core t-1 -
+    for t = 1 into the LAST core (its right bond is the boundary bond)."""
+    L = len(C)
+    logc = 0.0
+    for t in range(L - 1, -1, -1):
+        Ct = _reshape1(C[t])
+        q = Ct.shape[2]
+        M, logc = _rescale(Ct.reshape(Ct.shape[0], -1, order="F"), logc)
+        U, lam, V = svd_trunc(M)
+        k = len(lam)
+        C[t] = _reshapeas(V.T.reshape(k, -1, q, order="F"), C[t])
+        tp = (t - 1) % L
+        Cm = _reshape1(C[tp])
+        C[tp] = _reshapeas(np.transpose(np.tensordot(Cm, U * lam, axes=([1], [0])), (0, 2, 1)), C[tp])
+    C.logz -= logc
+    return C
+
+
+def orthogonalize_left(C, svd_trunc):
+    """[R] cyclic left sweep, the pattern of the in-tree periodic mpem2: t = 1..L, M[(m,x),n], core t <- U, carry
+    diag(lambda) V^T into core t+1 - for t = L into the FIRST core."""
+    L = len(C)
+    logc = 0.0
+    for t in range(L):
+        Ct = _reshape1(C[t])
+        q = Ct.shape[2]
+        M, logc = _rescale(np.transpose(Ct, (0, 2, 1)).reshape(-1, Ct.shape[1], order="F"), logc)
+        U, lam, V = svd_trunc(M)
+        k = len(lam)
+        C[t] = _reshapeas(np.transpose(U.reshape(-1, q, k, order="F"), (0, 2, 1)), C[t])
+        tn = (t + 1) % L
+        C[tn] = _reshapeas(np.tensordot((V * lam).T, _reshape1(C[tn]), axes=([1], [0])), C[tn])
+    C.logz -= logc
+    return C
+
+
+def compress(A, svd_trunc, is_orthogonal="none"):
+    """compress! on a periodic train: the same composition as for open chains (tensor_trains.compress)."""
+    if is_orthogonal == "none":
+        orthogonalize_right(A, TruncThresh(0.0))
+        orthogonalize_left(A, svd_trunc)
+    elif is_orthogonal == "left":
+        orthogonalize_right(A, svd_trunc)
+    else:
+        orthogonalize_left(A, svd_trunc)
+    return A
 
 
 def _chain_products(A):
@@ -215,13 +268,44 @@ def set_msg(bp, mu_j, edge_id, damp, svd_trunc):
     return logz
 
 
+def op_kron_compress(wi, a, b, T, svd_trunc):
+    """The `op` of compute_prob_ys (src/recursive_bp_factor.jl:118-131) on periodic trains: the Kronecker product acts on
+    the boundary bond as on any other; compress! is the periodic one [R]."""
+    B1, d1 = a
+    B2, d2 = b
+    cores = []
+    for t in range(T + 1):
+        w = wi[t]
+        b1, b2 = B1[t], B2[t]
+        ny = w.nstates(d1 + d2)
+        Pyy = np.zeros((ny, b1.shape[2], b2.shape[2], b1.shape[3]))
+        for y in range(ny):
+            for y1 in range(b1.shape[2]):
+                for y2 in range(b2.shape[2]):
+                    for xi in range(b1.shape[3]):
+                        Pyy[y, y1, y2, xi] = w.prob_yy(y + 1, y1 + 1, y2 + 1, xi + 1, d1, d2)
+        B3 = np.einsum("yabx,ipax,jqbx->ijpqyx", Pyy, b1, b2, optimize=True)
+        sh = B3.shape
+        cores.append(B3.reshape(sh[0] * sh[1], sh[2] * sh[3], sh[4], sh[5], order="F"))
+    Bout = TensorTrain(cores, B1.logz + B2.logz)
+    compress(Bout, svd_trunc)
+    normalize_eachmatrix(Bout)
+    return Bout, d1 + d2
+
+
+def compute_prob_ys(wi, qi, mu_in, psi_out, T, svd_trunc):
+    """src/recursive_bp_factor.jl:104-143 with the periodic `op`."""
+    B = [O.prob_xy_apply(wi, qi, mu_in[k], psi_out[k], k, T) for k in range(len(psi_out))]
+    dest, full = O.cavity(B, lambda a, b: op_kron_compress(wi, a, b, T, svd_trunc), O.init_train(wi, qi, T))
+    return [dd[0] for dd in dest], full[0]
+
+
 def onebpiter(bp, i, svd_trunc, damp=0.0):
-    """src/recursive_bp_factor.jl:146-165 on periodic trains (compute_prob_ys is the generic one: the Kronecker product,
-    compress! [R] and normalize_eachmatrix! act on the boundary bond as on any other)."""
+    """src/recursive_bp_factor.jl:146-165 on periodic trains."""
     g = bp.g
     ein, eout = g.inedges(i), g.outedges(i)
     wi, phi_i, di = bp.w[i], bp.phi[i], len(ein)
-    C, full = O.compute_prob_ys(wi, bp.nstates(i), [bp.mu[e[2]] for e in ein], [bp.psi[e[2]] for e in eout], bp.T, svd_trunc)
+    C, full = compute_prob_ys(wi, bp.nstates(i), [bp.mu[e[2]] for e in ein], [bp.psi[e[2]] for e in eout], bp.T, svd_trunc)
     sumlogz = 0.0
     for j, e in enumerate(eout):
         B = _f_bp_partial(C[j], wi, phi_i, di - 1, "prob_y_partial", bp.nstates(e[1]), j + 1)

@@ -298,6 +298,38 @@ def test_periodic_infinite_graph_matches_complete_graph_gpu():
     assert np.abs(pb_inf - pb_c).max() < 1e-7
 
 
+def test_periodic_loopy_damped_sweeps_match_periodic_oracle_gpu():
+    """Chains periodic in time on a LOOPY graph with damping, sweep by sweep, against the restated periodic path of the
+    reference (oracle/periodic.py: PeriodicMPEM3, periodic mpem2 / _f_bp_partial of src/mpems.jl:96-155 and
+    src/recursive_bp_factor.jl:89-101, damping through the ring-closed _compose) while NO truncation binds on either side:
+    the case of reference test/periodic.jl:70-110 (homogeneous Glauber, complete graph of 4 nodes, T = 2, damp 0.2).
+    The device keeps a message as an open train that carries x_i^1 (exact bond <= 4 at T = 2), the oracle as a ring with
+    a boundary bond (21 after the second damped sweep, cap 32): the same functions, so beliefs and pair beliefs agree to
+    rounding.  Under a BINDING cap the two representations truncate different matrices (TruncBond(10) as in
+    test/periodic.jl:87: 7e-3 on the beliefs after the second sweep, tools/periodic_compare.py,
+    profiles/r03_periodic_compare.txt) - that regime is unpinned, DESIGN.md section 7."""
+    from oracle import periodic as OP
+    T, k, m0, damp = 2, 3, 0.5, 0.2
+    N = k + 1
+    A = np.ones((N, N)) - np.eye(N)
+    phi_i = [np.array([(1 + m0) / 2, (1 - m0) / 2]) if t == 0 else np.ones(2) for t in range(T + 1)]
+    phi_i[1] = np.array([0.4, 0.6])
+    phi_i[T] = np.array([0.95, 0.05])
+    bp = M.periodic_mpbp(M.IndexedBiDiGraph(A), [[M.HomogeneousGlauberFactor(1.0, 0.0, 1.0)] * (T + 1)] * N, 2, T,
+                         phi=[phi_i] * N, max_bond=16)
+    obp = OP.periodic_mpbp(O.IndexedBiDiGraph(A), [[OF.HomogeneousGlauberFactor(1.0, 0.0, 1.0)] * (T + 1)] * N, [2] * N, T,
+                           phi=[phi_i] * N)
+    for s in range(2):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(16), tol=0.0, damp=damp)
+        OP.iterate(obp, 1, OT.TruncBond(32), damp=damp, jacobi=True)
+        assert max(max(m.bonds) for m in obp.mu) < 32                       # nothing was truncated in the ring form
+        assert _rel(_flat(M.beliefs(bp)), _flat(OP.beliefs(obp))) < 1e-10, f"sweep {s}"
+    pb, _ = M.pair_beliefs(bp)
+    opb, _ = OP.pair_beliefs(obp)
+    assert _rel(_flat(pb), _flat(opb)) < 1e-10
+    assert np.allclose(_fnodes(bp), obp.f, rtol=1e-9, atol=1e-11)
+
+
 def test_initial_bond_size_d_gpu():
     """`mpbp(...; d)` with d > 1 (src/mpbp.jl:60-70: `flat_mpem2(q, q, T; d)`): the same uniform function in a redundant
     bond, so the first sweeps must give what d = 1 gives."""
