@@ -68,6 +68,10 @@ static LookAhead* lookahead_streams() {
 // Launch sequence of one R-only QR over a batch whose dimensions `dims` are known on the host.
 // d_probs: device array of v2::QrProb (same order as dims).  force_tall: column-step panels even when they would fit.
 // aux2: every problem's scratch holds TWO AuxLay copies (auxd doubles apart) - required for the look-ahead.
+// (Tried and measured slower, round 3: cutting a many-problem batch into four groups that run this sequence on their own
+// streams, so that one group's panel chain runs beside another's trailing update - 6400 x 1600 x 16: 49.3 against 28.3 ms,
+// 7200 x 900 x 128: 82.5 against 73.6 ms; without disjoint CUs the chains' VALU-bound kernels share SIMDs with MFMA streams
+// and run at a third of their speed, profiles/r03_dp_pipe_probe.txt.)
 int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims>& dims, const v2::AuxLay& lay,
              bool force_tall, int* coop_err = nullptr, int coop_max_wgs = 128, int64_t aux2 = 0) {
   const int P = (int)dims.size();
@@ -99,12 +103,12 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
           const int twi = ((int64_t)nchunk * P <= 128) ? 0 : 1;
           const dim3 g(twi == 0 ? 4 : 1, nchunk, P);
           switch (p) {
-            case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0);
-                    hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0); break;
-            case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0);
-                    hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0); break;
-            default: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0);
-                     hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0); break;
+            case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0, 0);
+                    hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0, 0); break;
+            case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0, 0);
+                    hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0, 0); break;
+            default: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0, 0);
+                     hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, s, d_probs, L, jb, 1, twi, 0, 0); break;
           }
         }
       }
@@ -175,13 +179,11 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       hipStreamWaitEvent(la->sa, la->e_b, 0);
       trail_coop(la->sa, L, jb, 4, ntile4);
       hipEventRecord(la->e_a[la_par], la->sa);
-      // part 1 (the next block's panel tiles) behind part 2 of the previous block
+      // part 1 (the next block's panel tiles) behind part 2 of the previous block.  (Tiles 1..3 on a second stream of the
+      // same CUs beside the next panel's column steps: measured no faster, 41.9 against 41.0 ms.)
       if (!first) hipStreamWaitEvent(la->sb, la->e_a[la_par ^ 1], 0);
-      {
-        const dim3 g(16, nchunk, P);
-        hipLaunchKernelGGL(v2::k_trailW<4>, g, dim3(256), 0, la->sb, d_probs, L, jb, 0, 0, 0);
-        hipLaunchKernelGGL(v2::k_trailU<4>, g, dim3(256), 0, la->sb, d_probs, L, jb, 0, 0, 0);
-      }
+      hipLaunchKernelGGL(v2::k_trailW<4>, dim3(16, nchunk, P), dim3(256), 0, la->sb, d_probs, L, jb, 0, 0, 0, 0);
+      hipLaunchKernelGGL(v2::k_trailU<4>, dim3(16, nchunk, P), dim3(256), 0, la->sb, d_probs, L, jb, 0, 0, 0, 0);
       la_par ^= 1;
       continue;
     }
@@ -205,14 +207,14 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       if ((!fused && !coop) || kmax_min - jb < 64) {
         const dim3 g((ntile_max + 3) / 4, nchunk, P);
         switch (npmax) {
-          case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);
-                  hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short); break;
-          case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);
-                  hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short); break;
-          case 3: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);
-                  hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short); break;
-          default: hipLaunchKernelGGL(v2::k_trailW<4>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short);
-                   hipLaunchKernelGGL(v2::k_trailU<4>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short); break;
+          case 1: hipLaunchKernelGGL(v2::k_trailW<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short, 0);
+                  hipLaunchKernelGGL(v2::k_trailU<1>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short, 0); break;
+          case 2: hipLaunchKernelGGL(v2::k_trailW<2>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short, 0);
+                  hipLaunchKernelGGL(v2::k_trailU<2>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short, 0); break;
+          case 3: hipLaunchKernelGGL(v2::k_trailW<3>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short, 0);
+                  hipLaunchKernelGGL(v2::k_trailU<3>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short, 0); break;
+          default: hipLaunchKernelGGL(v2::k_trailW<4>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short, 0);
+                   hipLaunchKernelGGL(v2::k_trailU<4>, g, dim3(256), 0, st, d_probs, lay, jb, 0, 4, only_short, 0); break;
         }
       }
     }
@@ -220,6 +222,7 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
   la_leave();
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
 
 }  // namespace
 

@@ -632,7 +632,7 @@ __device__ __forceinline__ TrailGeom trail_geom(const QrProb& P, int jb, int NP,
 }
 
 template <int NP>
-__global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw, int only_short) {
+__global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw, int only_short, int tf0 = 0) {
   const QrProb P = probs[blockIdx.z];
   if (jb >= P.kmax) return;
   if (only_short && P.kmax - jb >= 64) return;        // k_trail4f has taken the problems with four panels
@@ -644,9 +644,9 @@ __global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay,
   // on the chip; the four waves' products are summed through LDS into the same slot layout (chunk * 4 + quarter)
   const bool fine = tw == 0;
   const int rw = fine ? 4 : 4 / tw;
-  // fine form: grid.x = 4 * tiles (the in-block update has one tile; the look-ahead of qr_batch updates the next block's
-  // four panel tiles this way, inblock = 0)
-  const int tile = fine ? (int)(blockIdx.x >> 2) : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)(blockIdx.x & 3) : wave / tw;
+  // fine form: grid.x = 4 * tiles, starting at tile tf0 (the in-block update has one tile; the look-ahead of qr_batch
+  // updates the next block's four panel tiles this way, inblock = 0)
+  const int tile = fine ? tf0 + (int)(blockIdx.x >> 2) : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)(blockIdx.x & 3) : wave / tw;
   if (tile >= G.ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) k_trailW(const QrProb* probs, AuxLay lay,
 }
 
 template <int NP>
-__global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw, int only_short) {
+__global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay, int jb, int inblock, int tw, int only_short, int tf0 = 0) {
   const QrProb P = probs[blockIdx.z];
   if (jb >= P.kmax) return;
   if (only_short && P.kmax - jb >= 64) return;
@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
   __syncthreads();
   const bool fine = tw == 0;                               // see k_trailW
   const int rw = fine ? 4 : 4 / tw;
-  const int tile = fine ? (int)(blockIdx.x >> 2) : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)(blockIdx.x & 3) : wave / tw;
+  const int tile = fine ? tf0 + (int)(blockIdx.x >> 2) : blockIdx.x * tw + (wave % tw), rsub = fine ? (int)(blockIdx.x & 3) : wave / tw;
   if (tile >= G.ntile) return;
   const int rows32 = (P.rows + 31) & ~31;
   const int chunk = blockIdx.y;
