@@ -35,7 +35,7 @@ struct QrDims { int rows, cols, kmax; };
 // block k-1 (which brought those columns up to block k-1); block k+1's chain writes the second copy of the per-problem
 // scratch (shift_auxlay) while part 2 of block k reads the first.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int LA_RESERVED = 64;      // CUs of the panel stream
+static const int LA_RESERVED = [] { const char* e = getenv("MPBP_LA_RESERVED"); const int v = e ? atoi(e) : 64; return (v >= 16 && v <= 128) ? v : 64; }();      // CUs of the panel stream
 constexpr int LA_MAX_WGS = 24;       // look-ahead only while the batch is latency bound: row-chunk workgroups of all its problems (6400 x 1600 x 16 with 64 of them is throughput bound and loses 20 % to the reserved CUs)
 struct LookAhead {
   hipStream_t sa = nullptr, sb = nullptr;
@@ -53,7 +53,7 @@ static LookAhead* lookahead_streams() {
     hipDeviceProp_t pr;
     if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return nullptr;
     const int ncu = pr.multiProcessorCount, words = (ncu + 31) / 32;
-    if (ncu < 4 * LA_RESERVED) return nullptr;
+    if (ncu < 2 * LA_RESERVED) return nullptr;
     std::vector<uint32_t> mb(words, 0u), ma(words, 0u);
     for (int i = 0; i < ncu; i++) (i < LA_RESERVED ? mb : ma)[i / 32] |= 1u << (i % 32);
     if (hipExtStreamCreateWithCUMask(&l.sa, words, ma.data()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
