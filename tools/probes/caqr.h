@@ -114,18 +114,36 @@ __device__ __forceinline__ void update_tile(gdbl* Y, long ld, int row0, int col0
     }
   }
   // ------------------------------------------------ phase A: W0_p = V_p^T C
+  // The LDS operands are fetched one row group ahead by hand and the schedule is pinned per group: left alone, the
+  // scheduler hoists dozens of ds_reads above the MFMA chain and spills the C tile (204 spills at NRB = 16).
   d4 w[4];
 #pragma unroll
   for (int p = 0; p < 4; p++) {
     d4 acc = d4{0, 0, 0, 0};
     if (p < np) {
+      // two base pointers per operand: the row-group offset (8 KB per group) then fits the 16-bit ds_read immediate;
+      // with one base the compiler materialises an address register per (group, e) - 204 of them, spilled
+      const ldbl* Vlo[4];
+      const ldbl* Vhi[4];
 #pragma unroll
-      for (int rb = 0; rb < NRB; rb++)
+      for (int e = 0; e < 4; e++) { Vlo[e] = V + ((p & 1) ? aO[e] : aE[e]); Vhi[e] = Vlo[e] + 8192; }      // the same 16 registers for every p
+      double a[4], an[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const double a = V[((p & 1) ? aO[e] : aE[e]) + 16 * p + 1024 * rb];
-          acc = mfma(a, C[rb][e], acc);
+      for (int e = 0; e < 4; e++) a[e] = Vlo[e][16 * p];
+#pragma unroll
+      for (int rb = 0; rb < NRB; rb++) {
+        if (rb + 1 < NRB) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) an[e] = (rb + 1 < 8) ? Vlo[e][16 * p + 1024 * (rb + 1)] : Vhi[e][16 * p + 1024 * (rb + 1 - 8)];
         }
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc = mfma(a[e], C[rb][e], acc);
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[e] = an[e];
+#ifndef CAQR_NO_SCHED_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
     }
     w[p] = acc;
   }
@@ -160,14 +178,20 @@ __device__ __forceinline__ void update_tile(gdbl* Y, long ld, int row0, int col0
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       if (p < np) {
+        double a[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-          const double a = V[((p & 1) ? cO[s] : cE[s]) + 16 * p + 1024 * rb];
-          acc = mfma(a, w[p][s], acc);
+          const ldbl* vb = V + ((p & 1) ? cO[s] : cE[s]) + ((rb < 8) ? 0 : 8192);
+          a[s] = vb[16 * p + 1024 * (rb & 7)];
         }
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = mfma(a[s], w[p][s], acc);
       }
     }
     __builtin_nontemporal_store(acc, reinterpret_cast<gd4*>(cp + 16 * rb));
+#ifndef CAQR_NO_SCHED_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
