@@ -1,0 +1,958 @@
+// Communication-avoiding form of the batched R-only QR (grid level): the gauge-sweep factorisation of the compress
+// engine for Y_t too tall for one workgroup (BASELINE configs[2..4]; reference: the orthogonalize_right! half of
+// `compress!` inside `op`, src/recursive_bp_factor.jl:127 - only R = Lf^T is kept, engine.h).
+//
+// The launch-per-panel Householder form (v2_kernels.h) applies full-height block reflectors: per 64 columns the trailing
+// matrix is read twice and written once, the reflectors are streamed twice, and the partial products of the row chunks
+// meet in memory.  Here every 64-column block is reduced by a 4-ary TREE of 256-row nodes (CAQR):
+//
+//   level 0   node = 256 consecutive rows from row 64 k on: plain Householder QR of its 256 x 64 piece of the block;
+//             its R (64 x 64) stays in the node's first 64 rows
+//   level l   node = the first 64 rows of four level l-1 nodes (four SEGMENTS of 64 rows): the same factorisation of
+//             the stacked R factors; the root's R lands in rows [64 k, 64 k + 64) - where R_k belongs
+//
+// so the reflectors of a node touch only the node's 256 rows.  Two kernels per level:
+//   k_cq_fac  one 256-thread workgroup per node: the 64 column steps entirely in registers (rows across lanes in the MFMA
+//             B-operand layout, a column's dot products are in-lane sums + two butterfly levels + one LDS exchange of the
+//             four waves), then the node's reflectors as an XOR-swizzled LDS image + the T / cross-Gram operand images
+//             (MFMA Gram of the image, dlarft recurrence), copied to the node's slot of the per-problem scratch
+//   k_cq_upd  workgroups over (tile group, node, problem): the image (148 KB) into LDS once, then every wave takes
+//             256 x 16 tiles of the trailing matrix: read ONCE into registers, W0 = V^T C, W = T-recurrence, C -= V W,
+//             written ONCE.  Measured alone (tools/probes/caqr_update_probe.hip): 60 % of the fp64 MFMA peak with 256
+//             workgroups streaming, against ~35 % for the streamed-reflector passes.
+// A level's update must precede the next level's (they share the segment rows); the factorisations of the levels only
+// depend on each other (they touch the block's own 64 columns).  The tree costs 1/3 more update flops than a
+// full-height reflector (the stacked triangles are treated as dense) - at more than twice the rate.
+//
+// Layouts (lane = 16 g + c):
+//   B/D layout of a 16-row group: lane (g, c) holds rows 4g + e (e = 0..3, one d4 = 32 contiguous bytes) of column c.
+//     As the B operand of k-step e the MFMA k index g stands for row 4g + e; as the accumulator D, register e of lane
+//     (g, c) is MFMA row g + 4e, which therefore also stands for row 4g + e: sigma(i) = 4 (i & 3) + (i >> 2).
+//   V image: V[row * 64 + (col ^ swz(row & 15))], swz(m) = (m & 3) | (m & 8) | ((m & 4) << 2)   (row = node row 0..255)
+//   operand images of the 16-column triangular factors T_p (p = 0..3) and the cross Grams S_pr (r < p):
+//     Timg[p][s][lane (g, c)] = T_p[4g + s][sigma(c)],  Simg[p,r][s][lane] = -S_pr[sigma(c)][4g + s]
+#pragma once
+
+namespace cq {
+using namespace wgc;
+
+constexpr int IMG_V = 256 * 64;             // doubles
+constexpr int IMG_OPS = 10 * 256;
+constexpr int IMG_DOUBLES = IMG_V + IMG_OPS;          // one node's slot in the scratch: 18944 doubles = 151,552 bytes
+// LDS of k_cq_fac behind the image
+constexpr int L_PART = IMG_DOUBLES;         // [2][4][64]
+constexpr int L_ROW = L_PART + 512;         // [2][64]
+constexpr int L_TAU = L_ROW + 128;          // [64]
+constexpr int L_FAC_TOTAL = L_TAU + 64;     // 19648 doubles = 157,184 bytes
+
+__device__ __forceinline__ int swz(int m) { return (m & 3) | (m & 8) | ((m & 4) << 2); }
+__device__ __forceinline__ int sig(int i) { return 4 * (i & 3) + (i >> 2); }
+
+// The node `node` of level `level` of block row offset j0 (= 64 k) in a matrix of rows32 rows: first row and valid row
+// count of its four 64-row segments.  Returns whether the node has work (level 0: any row; above: two children or more).
+__device__ __forceinline__ bool node_segments(int rows32, int j0, int level, int node, int (&base)[4], int (&cnt)[4]) {
+  long first, stride;
+  if (level == 0) { first = j0 + 256L * node; stride = 64; }
+  else {
+    long ls = 256;
+    for (int i = 1; i < level; i++) ls *= 4;
+    first = j0 + 4L * node * ls; stride = ls;
+  }
+  int nseg = 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const long b = first + stride * s;
+    const long n = (long)rows32 - b;
+    const int m = n > 64 ? 64 : (n > 0 ? (int)n : 0);
+    base[s] = m > 0 ? (int)b : j0;
+    cnt[s] = m;
+    nseg += (m > 0);
+  }
+  return level == 0 ? (cnt[0] > 0) : (nseg >= 2);
+}
+
+__device__ __forceinline__ double bperm(double x, int srclane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(srclane << 2, __double2loint(x));
+  const int hi = __builtin_amdgcn_ds_bpermute(srclane << 2, __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xor_add(double v, int mask) {
+  const int lane = threadIdx.x & 63;
+  return v + bperm(v, lane ^ mask);
+}
+
+struct Refl { double beta, tau, scale; };
+// LAPACK dlarfg from the pivot and the squared norm below it (rsq / rcp + Newton, as v2::reflector)
+__device__ __forceinline__ Refl dlarfg(double alpha, double ss) {
+  Refl r;
+  if (ss == 0.0) { r.beta = alpha; r.tau = 0.0; r.scale = 0.0; return r; }
+  const double n2 = alpha * alpha + ss;
+  double ri = __builtin_amdgcn_rsq(n2);
+  ri = ri * (1.5 - 0.5 * n2 * ri * ri);
+  ri = ri * (1.5 - 0.5 * n2 * ri * ri);              // 1 / ||x||
+  double nrm = n2 * ri;
+  nrm = nrm + 0.5 * ri * (n2 - nrm * nrm);           // ||x||
+  r.beta = -copysign(nrm, alpha);
+  r.tau = 1.0 + fabs(alpha) * ri;                    // (beta - alpha) / beta
+  const double dd = alpha - r.beta;                  // |dd| = |alpha| + ||x||: no cancellation
+  double rd = __builtin_amdgcn_rcp(dd);
+  rd = rd * (2.0 - dd * rd);
+  rd = rd * (2.0 - dd * rd);
+  r.scale = rd;
+  return r;
+}
+
+// The sixteen column steps of sub-panel PJ of a node.  P[rb][e][p]: node row 64 w + 16 rb + 4 g + e, block column
+// 16 p + c; the pivot rows are the node's first 64 rows (wave 0).  One workgroup barrier per column (the partial sums
+// and the pivot row are double buffered).
+template <int PJ>
+__device__ __forceinline__ void panel16(double (&P)[4][4][4], double (&mytau)[4], int w, ldbl* lds, int& step) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  ldbl* part = lds + L_PART;
+  ldbl* rowb = lds + L_ROW;
+  for (int cj = 0; cj < 16; cj++) {
+    const int j = 16 * PJ + cj;
+    const int par = step & 1;
+    step++;
+    const int src = (lane & 48) | cj;
+    double x[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        double v = bperm(P[rb][e][PJ], src);
+        const bool incl = (w > 0) || (rb > PJ) || (rb == PJ && 4 * g + e > cj);
+        x[rb][e] = incl ? v : 0.0;
+      }
+    // column sums of x .* P over this wave's rows
+    double d[4];
+#pragma unroll
+    for (int p = PJ; p < 4; p++) {
+      double s = 0.0;
+#pragma unroll
+      for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) s += x[rb][e] * P[rb][e][p];
+      s = xor_add(s, 16);
+      s = xor_add(s, 32);
+      d[p] = s;
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int p = PJ; p < 4; p++) part[par * 256 + w * 64 + 16 * p + c] = d[p];
+    }
+    // the pivot row of this step, columns of the block from sub-panel PJ on
+    if (w == 0 && g == (cj >> 2)) {
+      const int ee = cj & 3;
+#pragma unroll
+      for (int p = PJ; p < 4; p++) {
+        const double v = (ee == 0) ? P[PJ][0][p] : (ee == 1) ? P[PJ][1][p] : (ee == 2) ? P[PJ][2][p] : P[PJ][3][p];
+        rowb[par * 64 + 16 * p + c] = v;
+      }
+    }
+    lds_barrier();
+    double ss = 0.0, dt[4], rv[4];
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++) ss += part[par * 256 + ww * 64 + 16 * PJ + cj];
+#pragma unroll
+    for (int p = PJ; p < 4; p++) {
+      double s = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ww++) s += part[par * 256 + ww * 64 + 16 * p + c];
+      dt[p] = s;
+      rv[p] = rowb[par * 64 + 16 * p + c];
+    }
+    const double alpha = rowb[par * 64 + j];
+    const Refl h = dlarfg(alpha, ss);
+    mytau[PJ] = (c == cj) ? h.tau : mytau[PJ];
+    double tw[4];
+#pragma unroll
+    for (int p = PJ; p < 4; p++) {
+      const double t = h.tau * (rv[p] + h.scale * dt[p]);
+      tw[p] = (p == PJ && c <= cj) ? 0.0 : t;
+    }
+    const bool iscj = (c == cj);
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const double v = x[rb][e] * h.scale;
+        const bool incl = (w > 0) || (rb > PJ) || (rb == PJ && 4 * g + e > cj);
+        const double upd = P[rb][e][PJ] - v * tw[PJ];
+        P[rb][e][PJ] = (iscj && incl) ? v : upd;
+#pragma unroll
+        for (int p = PJ + 1; p < 4; p++) P[rb][e][p] -= v * tw[p];
+      }
+    // the pivot row itself: v = 1 there
+    if (w == 0 && g == (cj >> 2)) {
+      const int ee = cj & 3;
+#pragma unroll
+      for (int p = PJ; p < 4; p++) {
+        const double nv = (p == PJ && iscj) ? h.beta : (rv[p] - tw[p]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) P[PJ][e][p] = (e == ee) ? nv : P[PJ][e][p];
+      }
+    }
+  }
+}
+
+// T of a sixteen-reflector panel from its Gram matrix (dlarft): row i of T depends only on its own earlier entries.
+//   T(i,j) = -tau_j sum_{i2=i}^{j-1} T(i,i2) G(i2,j)  (i < j),  T(j,j) = tau_j.     G: plain 16 x 16, [i + 16 j]
+__device__ __forceinline__ void t_from_gram(const ldbl* G, const ldbl* tau, double (&trow)[16], int i) {
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    double gcol[16];
+#pragma unroll
+    for (int i2 = 0; i2 < 16; i2++) gcol[i2] = G[i2 + 16 * j];
+    const double tj = tau[j];
+    double sacc = 0.0;
+#pragma unroll
+    for (int i2 = 0; i2 < j; i2++) sacc += (i2 >= i) ? trow[i2] * gcol[i2] : 0.0;
+    trow[j] = (j == i) ? tj : ((j > i) ? -tj * sacc : 0.0);
+  }
+}
+
+// Gram blocks of the LDS image -> T_p and S_pr operand images.  Called by the four waves (u = 0..3) together; two barriers.
+//   blocks: 0..3 = (p,p); 4 + p(p-1)/2 + r = (p,r).  G_pr[i][j] = sum_rows V[row][16p+i] V[row][16r+j]
+__device__ __forceinline__ void build_images(int u, int nrb, int np, const ldbl* V, ldbl* OPS, const ldbl* tauL) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  for (int b = u; b < 10; b += 4) {
+    int p, r;
+    if (b < 4) { p = b; r = b; }
+    else { const int q = b - 4; p = (q < 1) ? 1 : ((q < 3) ? 2 : 3); r = q - p * (p - 1) / 2; }
+    ldbl* G = OPS + b * 256;
+    d4 acc = d4{0, 0, 0, 0};
+    if (p < np) {
+      for (int rb = 0; rb < nrb; rb++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int m = 4 * g + e, z = swz(m);
+          const double a = V[(16 * rb + m) * 64 + ((16 * p + c) ^ z)];
+          const double bb = V[(16 * rb + m) * 64 + ((16 * r + c) ^ z)];
+          acc = mfma(a, bb, acc);
+        }
+      }
+    }
+    // plain block: G[i = g + 4e][j = c]
+#pragma unroll
+    for (int e = 0; e < 4; e++) G[(g + 4 * e) + 16 * c] = acc[e];
+  }
+  lds_barrier();
+  // diagonal blocks -> T_p (wave u builds T_u), cross blocks -> image in place
+  for (int b = u; b < 10; b += 4) {
+    int p, r;
+    if (b < 4) { p = b; r = b; }
+    else { const int q = b - 4; p = (q < 1) ? 1 : ((q < 3) ? 2 : 3); r = q - p * (p - 1) / 2; }
+    (void)r;
+    ldbl* G = OPS + b * 256;
+    double img[4];
+    if (b < 4) {
+      double trow[16];
+      if (lane < 16) {
+        t_from_gram(G, tauL + 16 * p, trow, lane);
+#pragma unroll
+        for (int j = 0; j < 16; j++) G[lane + 16 * j] = trow[j];       // every lane has finished reading G (same wave, in order)
+      }
+      // Timg[s][lane (g, c)] = T[4g + s][sig(c)]
+#pragma unroll
+      for (int s = 0; s < 4; s++) img[s] = G[(4 * g + s) + 16 * sig(c)];
+    } else {
+      // Simg[s][lane] = -S_pr[sig(c)][4g + s]
+#pragma unroll
+      for (int s = 0; s < 4; s++) img[s] = -G[sig(c) + 16 * (4 * g + s)];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) G[64 * s + lane] = img[s];
+  }
+  lds_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_cq_fac: grid (nodes of the level, problems), 256 threads, L_FAC_TOTAL doubles of dynamic LDS.
+// ws_off: offset (doubles) of the node slots inside QrProb::aux; slot0: the level's first slot.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cq_fac(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0) {
+  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
+  ldbl* lds = (ldbl*)cq_lds_raw;
+  const v2::QrProb Pr = probs[blockIdx.y];
+  if (jb >= Pr.kmax) return;
+  const int rows32 = (Pr.rows + 31) & ~31;
+  int base[4], cnt[4];
+  if (!node_segments(rows32, jb, level, blockIdx.x, base, cnt)) return;
+  const int np = min(4, (Pr.kmax - jb + 15) >> 4);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  gdbl* Y = (gdbl*)Pr.Y;
+  const long ld = Pr.ld;
+  const int mybase = (w == 0) ? base[0] : (w == 1) ? base[1] : (w == 2) ? base[2] : base[3];
+  const int mycnt = (w == 0) ? cnt[0] : (w == 1) ? cnt[1] : (w == 2) ? cnt[2] : cnt[3];
+  ldbl* V = lds;
+  ldbl* OPS = lds + IMG_V;
+  ldbl* tauL = lds + L_TAU;
+
+  double P[4][4][4];
+  double mytau[4] = {0.0, 0.0, 0.0, 0.0};
+  {
+    const gdbl* src = Y + (long)(jb + c) * ld + mybase + 4 * g;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int rb = 0; rb < 4; rb++) {
+        d4 v = d4{0, 0, 0, 0};
+        if (p < np && 16 * rb < mycnt) v = *reinterpret_cast<const gd4*>(src + (long)(16 * p) * ld + 16 * rb);
+#pragma unroll
+        for (int e = 0; e < 4; e++) P[rb][e][p] = v[e];
+      }
+  }
+  int step = 0;
+  panel16<0>(P, mytau, w, lds, step);
+  if (np > 1) panel16<1>(P, mytau, w, lds, step);
+  if (np > 2) panel16<2>(P, mytau, w, lds, step);
+  if (np > 3) panel16<3>(P, mytau, w, lds, step);
+
+  // reflector image (unit lower trapezoidal head in the first 64 rows), taus, and R to its place
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int row = 64 * w + 16 * rb + 4 * g + e, col = 16 * p + c;
+        double v = P[rb][e][p];
+        if (w == 0) v = (row > col) ? v : ((row == col) ? 1.0 : 0.0);
+        if (16 * rb >= mycnt || p >= np) v = 0.0;
+        V[row * 64 + (col ^ swz(4 * g + e))] = v;
+      }
+  if (w == 0 && g == 0) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) tauL[16 * p + c] = mytau[p];
+  }
+  if (w == 0) {
+    gdbl* dst = Y + (long)(jb + c) * ld + mybase + 4 * g;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+      if (p < np) {
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+          if (16 * rb < mycnt) {
+            d4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (16 * rb + 4 * g + e <= 16 * p + c) ? P[rb][e][p] : 0.0;
+            *reinterpret_cast<gd4*>(dst + (long)(16 * p) * ld + 16 * rb) = v;
+          }
+        }
+      }
+  }
+  lds_barrier();
+  // no trailing columns: nobody reads the image
+  const int cols16 = (Pr.cols + 15) & ~15;
+  if (cols16 <= jb + 64) return;
+  const int nrb = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) >> 4;
+  build_images(w, nrb, np, V, OPS, tauL);
+  // image -> the node's slot
+  gd4* dstv = reinterpret_cast<gd4*>((gdbl*)Pr.aux + ws_off + (long)(slot0 + blockIdx.x) * IMG_DOUBLES);
+  typedef __attribute__((address_space(3))) d4 ld4;
+  const ld4* srcv = reinterpret_cast<const ld4*>(lds);
+  for (int i = tid; i < IMG_DOUBLES / 4; i += 256) __builtin_nontemporal_store(srcv[i], dstv + i);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Factorisation of a node, second form: the 64 columns as four 16-column SUB-PANELS.  The column steps touch only their
+// own sub-panel (VALU: a third of the work of updating all four at every step), the later sub-panels are brought up to
+// date with the sub-panel's block reflector on the matrix pipes (W0 = V^T C summed over the four waves through LDS,
+// W = T^T W0, C -= V W; C never leaves the registers).  A column is broadcast along its 16-lane row with DPP
+// (row_newbcast - one VALU move instead of a trip through the LDS crossbar), the partial dot products of all 16
+// (wave, row group) pairs meet in LDS with one barrier per column.
+// TREE: the node is a stack of four upper-triangular R factors, reflector j only touches rows <= j of segments 1..3
+// (the zero rows are skipped - 5/8 of the work on average).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int L2_PART = IMG_DOUBLES;        // [2][4][64]
+constexpr int L2_ROW = L2_PART + 512;       // [2][16]
+constexpr int L2_TAU = L2_ROW + 32;         // [64]
+constexpr int L2_FAC_TOTAL = L2_TAU + 64;   // 19552 doubles = 156,416 bytes
+constexpr int L2_SCR = IMG_V + 4 * 256;     // [4][256]: the cross-Gram slots of the operand images are free until the end
+
+template <int CJ>
+__device__ __forceinline__ double bcast16(double v) {
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + CJ, 0xf, 0xf, false);      // v_mov_b64_dpp row_newbcast:CJ
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// sum over the four 16-lane rows of the wave, in every lane (v_permlane32_swap / v_permlane16_swap: no LDS)
+__device__ __forceinline__ double reduce_rows(double s) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  {
+    const unsigned lo = __double2loint(s), hi = __double2hiint(s);
+    const u2v a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const u2v b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    s = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  {
+    const unsigned lo = __double2loint(s), hi = __double2hiint(s);
+    const u2v a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const u2v b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    s = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  return s;
+}
+
+template <int PJ, bool TREE, int CJ>
+__device__ __forceinline__ void bcast_col(const double (&P)[4][4][4], double (&x)[4][4]) {
+#pragma unroll
+  for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+#if defined(CQ_VAR) && CQ_VAR == 4
+    for (int e = 0; e < 4; e++) x[rb][e] = (TREE && rb > PJ) ? 0.0 : P[rb][e][PJ];
+#else
+    for (int e = 0; e < 4; e++) x[rb][e] = (TREE && rb > PJ) ? 0.0 : bcast16<CJ>(P[rb][e][PJ]);
+#endif
+}
+
+#ifdef CQ_PROF
+__device__ unsigned long long cq_prof[4][8];
+#define CQ_T(slot) do { const unsigned long long t1_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) cq_prof[w][slot] += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define CQ_T(slot) do {} while (0)
+#endif
+
+// The sixteen column steps of sub-panel PJ.  During the steps column cj keeps the UNSCALED vector x below its pivot (the
+// update of the other columns is P -= x (scale tw)); the columns are scaled to v = x scale once, after the last step.
+// MASK: some of this wave's rows are excluded (the first segment's rows up to the pivot; the zero rows of a triangle).
+template <int PJ, bool TREE, bool MASK>
+__device__ __forceinline__ void subpanel_steps_w(double (&P)[4][4][4], double (&mytau)[4], int w, ldbl* lds) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  ldbl* part = lds + L2_PART;
+  ldbl* rowb = lds + L2_ROW;
+  double myscale = 0.0;
+#ifdef CQ_PROF
+  unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+  for (int cj = 0; cj < 16; cj++) {
+    const int par = cj & 1;
+    double x[4][4];
+    switch (cj) {
+      case 0: bcast_col<PJ, TREE, 0>(P, x); break;   case 1: bcast_col<PJ, TREE, 1>(P, x); break;
+      case 2: bcast_col<PJ, TREE, 2>(P, x); break;   case 3: bcast_col<PJ, TREE, 3>(P, x); break;
+      case 4: bcast_col<PJ, TREE, 4>(P, x); break;   case 5: bcast_col<PJ, TREE, 5>(P, x); break;
+      case 6: bcast_col<PJ, TREE, 6>(P, x); break;   case 7: bcast_col<PJ, TREE, 7>(P, x); break;
+      case 8: bcast_col<PJ, TREE, 8>(P, x); break;   case 9: bcast_col<PJ, TREE, 9>(P, x); break;
+      case 10: bcast_col<PJ, TREE, 10>(P, x); break; case 11: bcast_col<PJ, TREE, 11>(P, x); break;
+      case 12: bcast_col<PJ, TREE, 12>(P, x); break; case 13: bcast_col<PJ, TREE, 13>(P, x); break;
+      case 14: bcast_col<PJ, TREE, 14>(P, x); break; default: bcast_col<PJ, TREE, 15>(P, x); break;
+    }
+    CQ_T(0);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+      if (TREE && rb > PJ) continue;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (MASK) {
+          bool incl;
+          if (TREE) incl = (rb < PJ || 4 * g + e <= cj);                              // segments 1..3 of a stack of triangles
+          else incl = (rb > PJ) || (rb == PJ && 4 * g + e > cj);                      // first segment of a dense node
+          x[rb][e] = incl ? x[rb][e] : 0.0;
+        }
+        if (e & 1) s1 += x[rb][e] * P[rb][e][PJ]; else s0 += x[rb][e] * P[rb][e][PJ];
+      }
+    }
+    const double sw = reduce_rows(s0 + s1);
+    if (g == 0) part[par * 64 + w * 16 + c] = sw;
+    if (w == 0 && g == (cj >> 2)) {
+      const int ee = cj & 3;
+      rowb[par * 16 + c] = (ee == 0) ? P[PJ][0][PJ] : (ee == 1) ? P[PJ][1][PJ] : (ee == 2) ? P[PJ][2][PJ] : P[PJ][3][PJ];
+    }
+    CQ_T(1);
+    lds_barrier();
+    CQ_T(2);
+    const double dt = (part[par * 64 + c] + part[par * 64 + 16 + c]) + (part[par * 64 + 32 + c] + part[par * 64 + 48 + c]);
+    const double rv = rowb[par * 16 + c];
+    const double ss = readlane_d(dt, cj), alpha = readlane_d(rv, cj);
+    CQ_T(3);
+    const Refl h = dlarfg(alpha, ss);
+    const bool iscj = (c == cj);
+    mytau[PJ] = iscj ? h.tau : mytau[PJ];
+    myscale = iscj ? h.scale : myscale;
+    const double tw = (c <= cj) ? 0.0 : h.tau * (rv + h.scale * dt);
+    const double tws = -h.scale * tw;
+    CQ_T(4);
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+      if (TREE && rb > PJ) continue;
+#pragma unroll
+      for (int e = 0; e < 4; e++) P[rb][e][PJ] += x[rb][e] * tws;
+    }
+    if (w == 0 && g == (cj >> 2)) {
+      const int ee = cj & 3;
+      const double nv = iscj ? h.beta : (rv - tw);
+#pragma unroll
+      for (int e = 0; e < 4; e++) P[PJ][e][PJ] = (e == ee) ? nv : P[PJ][e][PJ];
+    }
+    CQ_T(5);
+  }
+  // v = x scale below the pivots
+#pragma unroll
+  for (int rb = 0; rb < 4; rb++) {
+    if (TREE && rb > PJ) continue;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      bool incl = true;
+      if (MASK && !TREE) incl = (rb > PJ) || (rb == PJ && 4 * g + e > c);
+      P[rb][e][PJ] = incl ? P[rb][e][PJ] * myscale : P[rb][e][PJ];
+    }
+  }
+}
+
+// A wave of the first segment of a stack of triangles has no rows below the pivots: it only hands out the pivot rows.
+template <int PJ>
+__device__ __forceinline__ void subpanel_steps_pivots(double (&P)[4][4][4], double (&mytau)[4], ldbl* lds) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  ldbl* part = lds + L2_PART;
+  ldbl* rowb = lds + L2_ROW;
+  for (int cj = 0; cj < 16; cj++) {
+    const int par = cj & 1;
+    if (g == 0) part[par * 64 + c] = 0.0;
+    if (g == (cj >> 2)) {
+      const int ee = cj & 3;
+      rowb[par * 16 + c] = (ee == 0) ? P[PJ][0][PJ] : (ee == 1) ? P[PJ][1][PJ] : (ee == 2) ? P[PJ][2][PJ] : P[PJ][3][PJ];
+    }
+    lds_barrier();
+    const double dt = (part[par * 64 + c] + part[par * 64 + 16 + c]) + (part[par * 64 + 32 + c] + part[par * 64 + 48 + c]);
+    const double rv = rowb[par * 16 + c];
+    const double ss = readlane_d(dt, cj), alpha = readlane_d(rv, cj);
+    const Refl h = dlarfg(alpha, ss);
+    const bool iscj = (c == cj);
+    mytau[PJ] = iscj ? h.tau : mytau[PJ];
+    const double tw = (c <= cj) ? 0.0 : h.tau * (rv + h.scale * dt);
+    if (g == (cj >> 2)) {
+      const int ee = cj & 3;
+      const double nv = iscj ? h.beta : (rv - tw);
+#pragma unroll
+      for (int e = 0; e < 4; e++) P[PJ][e][PJ] = (e == ee) ? nv : P[PJ][e][PJ];
+    }
+  }
+}
+
+template <int PJ, bool TREE>
+__device__ __forceinline__ void subpanel_steps(double (&P)[4][4][4], double (&mytau)[4], int w, ldbl* lds) {
+  if (TREE) {
+    if (w == 0) subpanel_steps_pivots<PJ>(P, mytau, lds);
+    else subpanel_steps_w<PJ, true, true>(P, mytau, w, lds);
+  } else {
+    if (w == 0) subpanel_steps_w<PJ, false, true>(P, mytau, w, lds);
+    else subpanel_steps_w<PJ, false, false>(P, mytau, w, lds);
+  }
+}
+
+// T of a sixteen-reflector panel from its Gram matrix (dlarft) in registers: lane c of every 16-lane row holds row c of G
+// and builds row c of T; G(i2, j) of another row comes by DPP broadcast from lane i2.
+//   T(i,j) = -tau_j sum_{i2=i}^{j-1} T(i,i2) G(i2,j)  (i < j),  T(j,j) = tau_j   (T(i,i2) = 0 for i2 < i)
+template <int J, int I2>
+__device__ __forceinline__ void t_acc(const double (&grow)[16], const double (&trow)[16], double& sacc) {
+  if constexpr (I2 < J) { sacc += trow[I2] * bcast16<I2>(grow[J]); t_acc<J, I2 + 1>(grow, trow, sacc); }
+}
+template <int J>
+__device__ __forceinline__ void t_cols(const double (&grow)[16], double (&trow)[16], double tauc, int c) {
+  if constexpr (J < 16) {
+    const double tj = bcast16<J>(tauc);
+    double sacc = 0.0;
+    t_acc<J, 0>(grow, trow, sacc);
+    trow[J] = (J == c) ? tj : ((J > c) ? -tj * sacc : 0.0);
+    t_cols<J + 1>(grow, trow, tauc, c);
+  }
+}
+
+// After the column steps of sub-panel PJ: its reflectors into the LDS image, T_PJ (operand image in OPS slot PJ), and the
+// block-reflector update of the later sub-panels of the block in registers.
+template <int PJ, bool TREE>
+__device__ __forceinline__ void subpanel_finish(double (&P)[4][4][4], const double (&mytau)[4], int w, int mycnt, int np, ldbl* lds) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  ldbl* V = lds;
+  ldbl* OPS = lds + IMG_V;
+  ldbl* tauL = lds + L2_TAU;
+  ldbl* scr = lds + L2_SCR;
+  {
+    d4 acc = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int rl = 16 * rb + 4 * g + e, col = 16 * PJ + c;
+        double v = P[rb][e][PJ];
+        if (w == 0) v = (rl > col) ? v : ((rl == col) ? 1.0 : 0.0);
+        if (16 * rb >= mycnt) v = 0.0;
+        V[(64 * w + rl) * 64 + (col ^ swz(4 * g + e))] = v;
+        if (!(TREE && rb > PJ)) acc = mfma(v, v, acc);
+      }
+#pragma unroll
+    for (int e = 0; e < 4; e++) scr[w * 256 + 64 * e + lane] = acc[e];
+    if (w == 0 && g == 0) tauL[16 * PJ + c] = mytau[PJ];
+  }
+  lds_barrier();
+  if (w == 0) {
+    ldbl* G = OPS + PJ * 256;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      double sgm = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ww++) sgm += scr[ww * 256 + 64 * e + lane];
+      G[(g + 4 * e) + 16 * c] = sgm;
+    }
+    // dlarft recurrence with row c of G in registers and the entries of the other rows taken by DPP broadcast
+    double grow[16], trow[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) grow[j] = G[c + 16 * j];
+    t_cols<0>(grow, trow, mytau[PJ], c);
+    if (g == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) G[c + 16 * j] = trow[j];
+    }
+    double img[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) img[s] = G[(4 * g + s) + 16 * sig(c)];
+#pragma unroll
+    for (int s = 0; s < 4; s++) G[64 * s + lane] = img[s];
+  }
+  lds_barrier();
+  if (PJ < 3 && PJ + 1 < np) {
+    const int sc = sig(c);
+    double aA[4][4], aC[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+      if (TREE && rb > PJ) continue;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int m = 4 * g + e;
+        aA[rb][e] = V[(64 * w + 16 * rb + m) * 64 + ((16 * PJ + sc) ^ swz(m))];
+        aC[rb][e] = V[(64 * w + 16 * rb + sc) * 64 + ((16 * PJ + m) ^ swz(sc))];
+      }
+    }
+    double timg[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) timg[s] = OPS[PJ * 256 + 64 * s + lane];
+#pragma unroll
+    for (int p = PJ + 1; p < 4; p++) {
+      if (p < np) {
+        d4 acc = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+          if (TREE && rb > PJ) continue;
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc = mfma(aA[rb][e], P[rb][e][p], acc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) scr[w * 256 + 64 * e + lane] = acc[e];
+        lds_barrier();
+        d4 t = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          double sgm = 0.0;
+#pragma unroll
+          for (int ww = 0; ww < 4; ww++) sgm += scr[ww * 256 + 64 * e + lane];
+          t[e] = sgm;
+        }
+        d4 o = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; s++) o = mfma(timg[s], t[s], o);
+        o = -o;
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+          if (TREE && rb > PJ) continue;
+          d4 cc = d4{P[rb][0][p], P[rb][1][p], P[rb][2][p], P[rb][3][p]};
+#pragma unroll
+          for (int s = 0; s < 4; s++) cc = mfma(aC[rb][s], o[s], cc);
+#pragma unroll
+          for (int e = 0; e < 4; e++) P[rb][e][p] = cc[e];
+        }
+        lds_barrier();
+      }
+    }
+  }
+}
+
+// cross Grams of the finished image -> S_pr operand images (slots 4..9), shared out to the four waves
+__device__ __forceinline__ void build_cross(int u, int nrb, int np, const ldbl* V, ldbl* OPS) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  for (int b = 4 + u; b < 10; b += 4) {
+    const int q = b - 4;
+    const int p = (q < 1) ? 1 : ((q < 3) ? 2 : 3), r = q - p * (p - 1) / 2;
+    ldbl* G = OPS + b * 256;
+    d4 acc = d4{0, 0, 0, 0};
+    if (p < np) {
+      for (int rb = 0; rb < nrb; rb++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int m = 4 * g + e, z = swz(m);
+          const double a = V[(16 * rb + m) * 64 + ((16 * p + c) ^ z)];
+          const double bb = V[(16 * rb + m) * 64 + ((16 * r + c) ^ z)];
+          acc = mfma(a, bb, acc);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) G[(g + 4 * e) + 16 * c] = acc[e];
+    double img[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) img[s] = -G[sig(c) + 16 * (4 * g + s)];
+#pragma unroll
+    for (int s = 0; s < 4; s++) G[64 * s + lane] = img[s];
+  }
+}
+
+template <bool TREE>
+__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS);
+
+// k_cq_fac2: grid (nodes of the level, problems), 256 threads, L2_FAC_TOTAL doubles of dynamic LDS.
+// la != 0: the node also updates its rows of the NEXT block's 64 columns (tiles 0..3, one per wave), so that the next
+// block's factorisations depend on this launch chain only and the other tiles can follow on a second stream.
+template <bool TREE>
+__device__ __forceinline__ void fac2_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int slot, const int (&base)[4], const int (&cnt)[4],
+                                          int la, ldbl* lds) {
+  const int np = min(4, (Pr.kmax - jb + 15) >> 4);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  gdbl* Y = (gdbl*)Pr.Y;
+  const long ld = Pr.ld;
+  const int mybase = (w == 0) ? base[0] : (w == 1) ? base[1] : (w == 2) ? base[2] : base[3];
+  const int mycnt = (w == 0) ? cnt[0] : (w == 1) ? cnt[1] : (w == 2) ? cnt[2] : cnt[3];
+  ldbl* V = lds;
+  ldbl* OPS = lds + IMG_V;
+  const int cols16 = (Pr.cols + 15) & ~15;
+  const bool trailing = cols16 > jb + 64;
+
+  double P[4][4][4];
+  double mytau[4] = {0.0, 0.0, 0.0, 0.0};
+  {
+    const gdbl* src = Y + (long)(jb + c) * ld + mybase + 4 * g;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int rb = 0; rb < 4; rb++) {
+        d4 v = d4{0, 0, 0, 0};
+        if (p < np && 16 * rb < mycnt) v = *reinterpret_cast<const gd4*>(src + (long)(16 * p) * ld + 16 * rb);
+#pragma unroll
+        for (int e = 0; e < 4; e++) P[rb][e][p] = v[e];
+      }
+  }
+#if defined(CQ_VAR) && CQ_VAR == 5
+  subpanel_steps<0, TREE>(P, mytau, w, lds); subpanel_steps<1, TREE>(P, mytau, w, lds);
+  subpanel_steps<2, TREE>(P, mytau, w, lds); subpanel_steps<3, TREE>(P, mytau, w, lds);
+#else
+  subpanel_steps<0, TREE>(P, mytau, w, lds);
+  subpanel_finish<0, TREE>(P, mytau, w, mycnt, np, lds);
+  if (np > 1) { subpanel_steps<1, TREE>(P, mytau, w, lds); subpanel_finish<1, TREE>(P, mytau, w, mycnt, np, lds); }
+  if (np > 2) { subpanel_steps<2, TREE>(P, mytau, w, lds); subpanel_finish<2, TREE>(P, mytau, w, mycnt, np, lds); }
+  if (np > 3) { subpanel_steps<3, TREE>(P, mytau, w, lds); subpanel_finish<3, TREE>(P, mytau, w, mycnt, np, lds); }
+#endif
+  // R to its place (first segment: upper triangle, zeros below)
+  if (w == 0) {
+    gdbl* dst = Y + (long)(jb + c) * ld + mybase + 4 * g;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+      if (p < np) {
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+          if (16 * rb < mycnt) {
+            d4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (16 * rb + 4 * g + e <= 16 * p + c) ? P[rb][e][p] : 0.0;
+            *reinterpret_cast<gd4*>(dst + (long)(16 * p) * ld + 16 * rb) = v;
+          }
+        }
+      }
+  }
+  if (!trailing) return;
+  if (np < 4) {
+    // (cannot happen for rows >= cols: a block with trailing columns has four panels) - keep the image well defined
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+      if (p >= np) {
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) V[(64 * w + 16 * rb + 4 * g + e) * 64 + ((16 * p + c) ^ swz(4 * g + e))] = 0.0;
+        for (int i = lane; i < 256; i += 64) if (w == 0) OPS[p * 256 + i] = 0.0;
+      }
+    lds_barrier();
+  }
+  const int nrb = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) >> 4;
+  build_cross(w, nrb, np, V, OPS);
+  lds_barrier();
+  // image -> the node's slot
+  {
+    gd4* dstv = reinterpret_cast<gd4*>((gdbl*)Pr.aux + ws_off + (long)slot * IMG_DOUBLES);
+    typedef __attribute__((address_space(3))) d4 ld4;
+    const ld4* srcv = reinterpret_cast<const ld4*>(lds);
+    for (int i = tid; i < IMG_DOUBLES / 4; i += 256) __builtin_nontemporal_store(srcv[i], dstv + i);
+  }
+  if (la) {
+    const int col0 = jb + 64 + 16 * w;
+    if (col0 < cols16) update_tile<TREE>(Y, ld, base, nrb, col0, V, OPS);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_cq_fac2(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int la) {
+  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
+  ldbl* lds = (ldbl*)cq_lds_raw;
+  const v2::QrProb Pr = probs[blockIdx.y];
+  if (jb >= Pr.kmax) return;
+  const int rows32 = (Pr.rows + 31) & ~31;
+  int base[4], cnt[4];
+  if (!node_segments(rows32, jb, level, blockIdx.x, base, cnt)) return;
+#ifdef CQ_REPS
+  for (int rep = 0; rep < CQ_REPS; rep++) {            // probe builds: the same node again and again (warm instruction cache)
+    if (level == 0) fac2_body<false>(Pr, ws_off, jb, slot0 + blockIdx.x, base, cnt, la, lds);
+    else fac2_body<true>(Pr, ws_off, jb, slot0 + blockIdx.x, base, cnt, la, lds);
+    __syncthreads();
+  }
+  return;
+#endif
+  if (level == 0) fac2_body<false>(Pr, ws_off, jb, slot0 + blockIdx.x, base, cnt, la, lds);
+  else fac2_body<true>(Pr, ws_off, jb, slot0 + blockIdx.x, base, cnt, la, lds);
+}
+
+// One trailing tile (256 node rows in four segments x 16 columns at col0) against the node's LDS image.
+// nrb: valid 16-row groups (a prefix of the node's rows).
+// TREE: the node is a stack of four triangles - sub-panel p of the image is zero in the row groups (rb & 3) > p of every
+// segment, those products are skipped (5/8 of the MFMAs remain).
+constexpr bool tree_skip(bool tree, int rb, int p) { return tree && (rb & 3) > p; }
+constexpr int tree_next(bool tree, int rb, int p) {          // the next row group after rb that sub-panel p touches (16: none)
+  for (int r = rb + 1; r < 16; r++) if (!tree_skip(tree, r, p)) return r;
+  return 16;
+}
+template <bool TREE>
+__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  gdbl* cp = Y + (long)(col0 + c) * ld + 4 * g;
+  d4 C[16];
+#pragma unroll
+  for (int rb = 0; rb < 16; rb++) {
+    C[rb] = d4{0, 0, 0, 0};
+    if (rb < nrb) C[rb] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
+  }
+  // LDS offsets: p even / odd variants absorb the bit-4 part of the swizzle
+  int aE[4], aO[4], cE[4], cO[4];
+  {
+    const int sc = sig(c);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int m = 4 * g + e, z = swz(m);
+      const int lo = m * 64 + (sc ^ (z & 15)), hi = 16 * (z >> 4);
+      aE[e] = lo + hi; aO[e] = lo - hi;
+    }
+    const int z = swz(sc);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int lo = sc * 64 + ((4 * g + s) ^ (z & 15)), hi = 16 * (z >> 4);
+      cE[s] = lo + hi; cO[s] = lo - hi;
+    }
+  }
+  // ------------------------------------------------ phase A: W0_p = V_p^T C
+  // The LDS operands are fetched one row group ahead by hand and the schedule is pinned per group: left alone, the
+  // scheduler hoists dozens of ds_reads above the MFMA chain and spills the C tile.
+  d4 w[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    d4 acc = d4{0, 0, 0, 0};
+    // two base pointers per operand: the row-group offset (8 KB per group) then fits the 16-bit ds_read immediate;
+    // with one base the compiler materialises an address register per (group, e) - 204 of them, spilled
+    const ldbl* Vlo[4];
+    const ldbl* Vhi[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { Vlo[e] = V + ((p & 1) ? aO[e] : aE[e]); Vhi[e] = Vlo[e] + 8192; }
+    double a[4], an[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) a[e] = Vlo[e][16 * p];                       // row group 0 is never skipped
+#pragma unroll
+    for (int rb = 0; rb < 16; rb++) {
+      if (tree_skip(TREE, rb, p)) continue;
+      const int nx = tree_next(TREE, rb, p);
+      if (nx < 16) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) an[e] = (nx < 8) ? Vlo[e][16 * p + 1024 * nx] : Vhi[e][16 * p + 1024 * (nx - 8)];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc = mfma(a[e], C[rb][e], acc);
+#pragma unroll
+      for (int e = 0; e < 4; e++) a[e] = an[e];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    w[p] = acc;
+  }
+  // ------------------------------------------------ phase B: W_p = T_p^T (W0_p - sum_{r<p} S_pr W_r)
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    d4 t = w[p];
+#pragma unroll
+    for (int r = 0; r < p; r++) {
+      const ldbl* S = OPS + (4 + p * (p - 1) / 2 + r) * 256 + lane;
+#pragma unroll
+      for (int s = 0; s < 4; s++) t = mfma(S[64 * s], w[r][s], t);
+    }
+    d4 o = d4{0, 0, 0, 0};
+    const ldbl* T = OPS + p * 256 + lane;
+#pragma unroll
+    for (int s = 0; s < 4; s++) o = mfma(T[64 * s], t[s], o);
+    w[p] = o;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; p++) w[p] = -w[p];
+  // ------------------------------------------------ phase C: C -= sum_p V_p W_p
+#pragma unroll
+  for (int rb = 0; rb < 16; rb++) {
+    d4 acc = C[rb];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      if (tree_skip(TREE, rb, p)) continue;
+      double a[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const ldbl* vb = V + ((p & 1) ? cO[s] : cE[s]) + ((rb < 8) ? 0 : 8192);
+        a[s] = vb[16 * p + 1024 * (rb & 7)];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; s++) acc = mfma(a[s], w[p][s], acc);
+    }
+    if (rb < nrb) __builtin_nontemporal_store(acc, reinterpret_cast<gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_cq_upd: grid (tile groups, nodes of the level, problems), 512 threads, IMG_DOUBLES doubles of dynamic LDS.
+// Tiles [blockIdx.x * tpg, + tpg) of the columns right of the block, one per wave at a time.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_cq_upd(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int tpg, int tfirst) {
+  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
+  ldbl* lds = (ldbl*)cq_lds_raw;
+  const v2::QrProb Pr = probs[blockIdx.z];
+  const int cols16 = (Pr.cols + 15) & ~15;
+  if (jb + 64 > Pr.kmax || cols16 <= jb + 64) return;
+  const int ntl = (cols16 - jb - 64) >> 4;
+  const int t0 = tfirst + blockIdx.x * tpg;
+  if (t0 >= ntl) return;
+  const int rows32 = (Pr.rows + 31) & ~31;
+  int base[4], cnt[4];
+  if (!node_segments(rows32, jb, level, blockIdx.y, base, cnt)) return;
+  const int nrb = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) >> 4;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthr = blockDim.x, nwave = nthr >> 6;          // 512 threads, or 256 where a level has too few tiles for 8 waves per workgroup
+  {
+    const gd4* srcv = reinterpret_cast<const gd4*>((const gdbl*)Pr.aux + ws_off + (long)(slot0 + blockIdx.y) * IMG_DOUBLES);
+    typedef __attribute__((address_space(3))) d4 ld4;
+    ld4* dstv = reinterpret_cast<ld4*>(lds);
+    for (int i = tid; i < IMG_DOUBLES / 4; i += nthr) dstv[i] = srcv[i];
+  }
+  __syncthreads();
+  const int t1 = min(t0 + tpg, ntl);
+  if (level == 0) {
+    for (int t = t0 + wave; t < t1; t += nwave) update_tile<false>((gdbl*)Pr.Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V);
+  } else {
+    for (int t = t0 + wave; t < t1; t += nwave) update_tile<true>((gdbl*)Pr.Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V);
+  }
+}
+
+}  // namespace cq

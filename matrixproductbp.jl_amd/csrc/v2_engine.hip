@@ -10,6 +10,7 @@ namespace v512 {
 #undef WG_WAVES
 #include "engine_types.h"
 #include "v2_kernels.h"
+#include "cq_kernels.h"
 #include "ctx.h"
 #include "v2_engine.h"
 
@@ -40,6 +41,7 @@ constexpr int LA_MAX_WGS = 24;       // look-ahead only while the batch is laten
 struct LookAhead {
   hipStream_t sa = nullptr, sb = nullptr;
   hipEvent_t e_in = nullptr, e_a[2] = {nullptr, nullptr}, e_b = nullptr, e_out_a = nullptr, e_out_b = nullptr;
+  hipEvent_t e_cq[10] = {};          // communication-avoiding form: [0] hand-over to the two streams, [1..8] factorisation of a level done, [9] block done
   bool ok = false, tried = false;
 };
 static LookAhead* lookahead_streams() {
@@ -60,6 +62,7 @@ static LookAhead* lookahead_streams() {
     if (hipExtStreamCreateWithCUMask(&l.sb, words, mb.data()) != hipSuccess) { (void)hipGetLastError(); hipStreamDestroy(l.sa); return nullptr; }
     bool ev = true;
     for (hipEvent_t* e : {&l.e_in, &l.e_a[0], &l.e_a[1], &l.e_b, &l.e_out_a, &l.e_out_b}) ev = ev && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    for (hipEvent_t& e : l.e_cq) ev = ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     l.ok = ev;
   }
   return l.ok ? &l : nullptr;
@@ -151,6 +154,85 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
   LookAhead* la = (aux2 > 0 && coop_err && !no_coop && !getenv("MPBP_DEBUG_NO_COOP_TRAIL")) ? lookahead_streams() : nullptr;
   const bool la_shape = la && (int64_t)nchunk * P <= LA_MAX_WGS && rows32_max > 2 * v2::CH && kmax_min == kmax_max;
   const v2::AuxLay lay2[2] = {lay, v2::shift_auxlay(lay, aux2)};
+
+  // ---- communication-avoiding form (cq_kernels.h): tall problems, every one with rows >= cols; the node slots live in
+  //      the per-problem scratch behind the fixed header (lay.part on: partial products / Grams / W0 of the other form)
+  {
+    static const bool no_cq = getenv("MPBP_DEBUG_NO_CAQR") != nullptr;
+    bool tall_all = true;
+    for (const QrDims& d : dims) tall_all = tall_all && d.rows >= d.cols;
+    int64_t slots = 0;
+    for (int n = (rows32_max + 255) / 256;; n = (n + 3) / 4) { slots += n; if (n == 1) break; }
+    const int64_t ws_off = lay.part;
+    if (!no_cq && !force_tall && aux2 > 0 && tall_all && rows32_max > v2::CH && ws_off + slots * cq::IMG_DOUBLES <= 2 * aux2) {
+      hipFuncSetAttribute((const void*)cq::k_cq_fac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::L_FAC_TOTAL * 8);
+      hipFuncSetAttribute((const void*)cq::k_cq_upd, hipFuncAttributeMaxDynamicSharedMemorySize, cq::IMG_DOUBLES * 8);
+      hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::L2_FAC_TOTAL * 8);
+      static const bool fac1 = getenv("MPBP_DEBUG_CQ_FAC1") != nullptr;
+      int ncu = 256;
+      { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; }
+      const int cols16_max = r16i(cols_max);
+      // Two CU-masked streams for the upper levels of the tree (lookahead_streams: sb owns LA_RESERVED CUs, sa the rest):
+      // the factorisation of level l+1 only needs the R factors of level l, so the short chain F_{b+1} -> F_{b+2} -> ...
+      // of the levels whose nodes fit the reserved CUs runs on sb BESIDE the updates U_b, U_{b+1}, ... on sa.  Levels with
+      // more nodes than that fill the chip by themselves and stay on the caller's stream, one after the other.
+      LookAhead* la2 = (coop_err && !getenv("MPBP_DEBUG_CQ_SERIAL")) ? lookahead_streams() : nullptr;
+      auto fac = [&](hipStream_t s, int n, int jb, int level, int slot) {
+        if (fac1) hipLaunchKernelGGL(cq::k_cq_fac, dim3(n, P), dim3(256), cq::L_FAC_TOTAL * 8, s, d_probs, ws_off, jb, level, slot);
+        else hipLaunchKernelGGL(cq::k_cq_fac2, dim3(n, P), dim3(256), cq::L2_FAC_TOTAL * 8, s, d_probs, ws_off, jb, level, slot, 0);
+      };
+      auto upd = [&](hipStream_t s, int cus, int n, int ntl, int jb, int level, int slot) {
+        if (ntl <= 0) return;
+        // tiles per workgroup: one round over the CUs where the level's tiles allow it (one tile per wave and four-wave
+        // workgroups for the small upper levels), else up to four tiles per wave
+        const int64_t tiles = (int64_t)ntl * n * P;
+        int tpg = 8, nthr = 512;
+        if (tiles <= 4 * cus) { tpg = 4; nthr = 256; }
+        else {
+          // fewest (rounds over the CUs) x (time of a workgroup: ~12 us of image load + 6.2 us per tile, measured with the
+          // chip full): the number of tile groups decides how the last round is filled
+          double best = 1e30;
+          for (int g = 1; g <= (ntl + 7) / 8; g++) {
+            const int t = (ntl + g - 1) / g;
+            if (t > 64) continue;
+            const int64_t wgs = (int64_t)((ntl + t - 1) / t) * n * P;
+            const double cost = (double)((wgs + cus - 1) / cus) * (12.0 + 6.2 * t);
+            if (cost < best) { best = cost; tpg = t; }
+          }
+        }
+        hipLaunchKernelGGL(cq::k_cq_upd, dim3((ntl + tpg - 1) / tpg, n, P), dim3(nthr), cq::IMG_DOUBLES * 8, s, d_probs, ws_off, jb, level, slot, tpg, 0);
+      };
+      for (int jb = 0; jb < kmax_max; jb += 64) {
+        const int ntl = cols16_max > jb + 64 ? (cols16_max - jb - 64) / 16 : 0;
+        int nl[10], nlev = 0;
+        for (int n = (rows32_max - jb + 255) / 256; nlev < 10; n = (n + 3) / 4) { nl[nlev++] = n; if (n == 1) break; }
+        // b: the last level that stays on the caller's stream
+        int b = nlev - 1;
+        if (la2 && ntl > 0 && nlev <= 9) { b = 0; while (b + 1 < nlev && (int64_t)nl[b + 1] * P > LA_RESERVED) b++; }
+        int slot = 0;
+        for (int level = 0; level <= b; level++) {
+          fac(st, nl[level], jb, level, slot);
+          if (level < b || b == nlev - 1) upd(st, ncu, nl[level], ntl, jb, level, slot);
+          slot += nl[level];
+        }
+        if (b < nlev - 1) {
+          hipEventRecord(la2->e_cq[0], st);
+          hipStreamWaitEvent(la2->sa, la2->e_cq[0], 0); hipStreamWaitEvent(la2->sb, la2->e_cq[0], 0);
+          upd(la2->sa, ncu - LA_RESERVED, nl[b], ntl, jb, b, slot - nl[b]);
+          for (int level = b + 1; level < nlev; level++) {
+            fac(la2->sb, nl[level], jb, level, slot);
+            hipEventRecord(la2->e_cq[level], la2->sb);
+            hipStreamWaitEvent(la2->sa, la2->e_cq[level], 0);
+            upd(la2->sa, ncu - LA_RESERVED, nl[level], ntl, jb, level, slot);
+            slot += nl[level];
+          }
+          hipEventRecord(la2->e_cq[9], la2->sa);
+          hipStreamWaitEvent(st, la2->e_cq[9], 0);
+        }
+      }
+      return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+  }
   bool la_on = false;
   int la_par = 0;
   auto la_leave = [&]() {
