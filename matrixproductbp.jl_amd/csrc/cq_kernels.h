@@ -823,16 +823,28 @@ constexpr int tree_next(bool tree, int rb, int p) {          // the next row gro
   for (int r = rb + 1; r < 16; r++) if (!tree_skip(tree, r, p)) return r;
   return 16;
 }
-template <bool TREE>
-__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS) {
+__device__ __forceinline__ void load_tile(const gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16]) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  gdbl* cp = Y + (long)(col0 + c) * ld + 4 * g;
-  d4 C[16];
+  const gdbl* cp = Y + (long)(col0 + c) * ld + 4 * g;
 #pragma unroll
   for (int rb = 0; rb < 16; rb++) {
     C[rb] = d4{0, 0, 0, 0};
     if (rb < nrb) C[rb] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
   }
+}
+template <bool TREE>
+__device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS);
+template <bool TREE>
+__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS) {
+  d4 C[16];
+  load_tile(Y, ld, base, nrb, col0, C);
+  compute_tile<TREE>(Y, ld, base, nrb, col0, C, V, OPS);
+}
+// the tile in C (load_tile) against the node's image; the updated tile is stored
+template <bool TREE>
+__device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  gdbl* cp = Y + (long)(col0 + c) * ld + 4 * g;
   // LDS offsets: p even / odd variants absorb the bit-4 part of the swizzle
   int aE[4], aO[4], cE[4], cO[4];
   {
@@ -922,37 +934,74 @@ __device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_cq_upd: grid (tile groups, nodes of the level, problems), 512 threads, IMG_DOUBLES doubles of dynamic LDS.
-// Tiles [blockIdx.x * tpg, + tpg) of the columns right of the block, one per wave at a time.
+// k_cq_upd: grid (tile groups, nodes of the level, problems), 512 or 256 threads, IMG_DOUBLES doubles of dynamic LDS.
+// Tiles [tfirst + tg * tpg, + tpg) of the columns right of the block, one per wave at a time.
+// (Tried: four-wave workgroups that fetch the next tile while the current one is updated, two tile buffers in the 512
+// registers of a lone wave - the allocator spills 57-206 registers around the two buffers and the kernel is 8 % slower.)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) k_cq_upd(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int tpg, int tfirst) {
-  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
-  ldbl* lds = (ldbl*)cq_lds_raw;
-  const v2::QrProb Pr = probs[blockIdx.z];
+template <int NT>
+__device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int level, int slot, int node, int tg, int tpg,
+                                         int tfirst, ldbl* lds) {
   const int cols16 = (Pr.cols + 15) & ~15;
   if (jb + 64 > Pr.kmax || cols16 <= jb + 64) return;
   const int ntl = (cols16 - jb - 64) >> 4;
-  const int t0 = tfirst + blockIdx.x * tpg;
+  const int t0 = tfirst + tg * tpg;
   if (t0 >= ntl) return;
   const int rows32 = (Pr.rows + 31) & ~31;
   int base[4], cnt[4];
-  if (!node_segments(rows32, jb, level, blockIdx.y, base, cnt)) return;
+  if (!node_segments(rows32, jb, level, node, base, cnt)) return;
   const int nrb = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) >> 4;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nthr = blockDim.x, nwave = nthr >> 6;          // 512 threads, or 256 where a level has too few tiles for 8 waves per workgroup
+  constexpr int nwave = NT >> 6;
   {
-    const gd4* srcv = reinterpret_cast<const gd4*>((const gdbl*)Pr.aux + ws_off + (long)(slot0 + blockIdx.y) * IMG_DOUBLES);
+    const gd4* srcv = reinterpret_cast<const gd4*>((const gdbl*)Pr.aux + ws_off + (long)slot * IMG_DOUBLES);
     typedef __attribute__((address_space(3))) d4 ld4;
     ld4* dstv = reinterpret_cast<ld4*>(lds);
-    for (int i = tid; i < IMG_DOUBLES / 4; i += nthr) dstv[i] = srcv[i];
+    for (int i = tid; i < IMG_DOUBLES / 4; i += NT) dstv[i] = srcv[i];
   }
   __syncthreads();
   const int t1 = min(t0 + tpg, ntl);
+  gdbl* Y = (gdbl*)Pr.Y;
   if (level == 0) {
-    for (int t = t0 + wave; t < t1; t += nwave) update_tile<false>((gdbl*)Pr.Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V);
+    for (int t = t0 + wave; t < t1; t += nwave) update_tile<false>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V);
   } else {
-    for (int t = t0 + wave; t < t1; t += nwave) update_tile<true>((gdbl*)Pr.Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V);
+    for (int t = t0 + wave; t < t1; t += nwave) update_tile<true>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V);
   }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_cq_upd(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int tpg, int tfirst) {
+  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
+  upd_body<NT>(probs[blockIdx.z], ws_off, jb, level, slot0 + blockIdx.y, blockIdx.y, blockIdx.x, tpg, tfirst, (ldbl*)cq_lds_raw);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_cq_updfac: the update of level `level` AND the factorisation of level `level + 1` in one launch (256 threads,
+// L2_FAC_TOTAL doubles of dynamic LDS).  The two do not touch the same data (the factorisation works on the block's own
+// 64 columns and only needs the R factors the previous launch left there, the update works on the columns to the
+// right), and the few factor workgroups - first in the grid, so they start at once - run on CUs of their own beside
+// the update's instead of holding the whole chip for 70 us per level.  Two streams do not give this: the hand-over
+// between them costs 20-40 us per event (see qr_batch).
+// grid.x = nprob * nfac + nprob * nupd * ntg  (nfac / nupd: nodes of level + 1 / level, ntg: tile groups)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cq_updfac(const v2::QrProb* probs, int nprob, int64_t ws_off, int jb, int level, int slot_u, int nupd,
+                                                   int ntg, int tpg, int slot_f, int nfac) {
+  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
+  ldbl* lds = (ldbl*)cq_lds_raw;
+  int b = blockIdx.x;
+  if (b < nprob * nfac) {
+    const int node = b % nfac;
+    const v2::QrProb Pr = probs[b / nfac];
+    if (jb >= Pr.kmax) return;
+    const int rows32 = (Pr.rows + 31) & ~31;
+    int base[4], cnt[4];
+    if (!node_segments(rows32, jb, level + 1, node, base, cnt)) return;
+    fac2_body<true>(Pr, ws_off, jb, slot_f + node, base, cnt, 0, lds);
+    return;
+  }
+  b -= nprob * nfac;
+  const int tg = b % ntg, node = (b / ntg) % nupd;
+  upd_body<256>(probs[b / (ntg * nupd)], ws_off, jb, level, slot_u + node, node, tg, tpg, 0, lds);
 }
 
 }  // namespace cq

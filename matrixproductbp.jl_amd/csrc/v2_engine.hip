@@ -41,7 +41,6 @@ constexpr int LA_MAX_WGS = 24;       // look-ahead only while the batch is laten
 struct LookAhead {
   hipStream_t sa = nullptr, sb = nullptr;
   hipEvent_t e_in = nullptr, e_a[2] = {nullptr, nullptr}, e_b = nullptr, e_out_a = nullptr, e_out_b = nullptr;
-  hipEvent_t e_cq[10] = {};          // communication-avoiding form: [0] hand-over to the two streams, [1..8] factorisation of a level done, [9] block done
   bool ok = false, tried = false;
 };
 static LookAhead* lookahead_streams() {
@@ -62,7 +61,6 @@ static LookAhead* lookahead_streams() {
     if (hipExtStreamCreateWithCUMask(&l.sb, words, mb.data()) != hipSuccess) { (void)hipGetLastError(); hipStreamDestroy(l.sa); return nullptr; }
     bool ev = true;
     for (hipEvent_t* e : {&l.e_in, &l.e_a[0], &l.e_a[1], &l.e_b, &l.e_out_a, &l.e_out_b}) ev = ev && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-    for (hipEvent_t& e : l.e_cq) ev = ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     l.ok = ev;
   }
   return l.ok ? &l : nullptr;
@@ -165,69 +163,60 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
     for (int n = (rows32_max + 255) / 256;; n = (n + 3) / 4) { slots += n; if (n == 1) break; }
     const int64_t ws_off = lay.part;
     if (!no_cq && !force_tall && aux2 > 0 && tall_all && rows32_max > v2::CH && ws_off + slots * cq::IMG_DOUBLES <= 2 * aux2) {
-      hipFuncSetAttribute((const void*)cq::k_cq_fac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::L_FAC_TOTAL * 8);
-      hipFuncSetAttribute((const void*)cq::k_cq_upd, hipFuncAttributeMaxDynamicSharedMemorySize, cq::IMG_DOUBLES * 8);
+      hipFuncSetAttribute((const void*)cq::k_cq_upd<512>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::IMG_DOUBLES * 8);
+      hipFuncSetAttribute((const void*)cq::k_cq_upd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::IMG_DOUBLES * 8);
       hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::L2_FAC_TOTAL * 8);
-      static const bool fac1 = getenv("MPBP_DEBUG_CQ_FAC1") != nullptr;
       int ncu = 256;
       { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; }
+      // One stream, one launch after the other.  Measured and dropped (round 3): (a) the upper-level factorisations of a
+      // single problem on a CU-masked stream beside the updates - the 20-40 us per event hand-over and the CUs taken from
+      // the updates cost what the overlap gained (16384 x 4096: 43.9 against 44.4 ms at the time); (b) the batch cut into
+      // 2 / 4 groups of problems on their own streams, so that one group's narrow launches fill CUs beside another's wide
+      // ones: 6400 x 1600 x 16 26.9 -> 28.0 / 34.5 ms, 7200 x 900 x 128 69.9 -> 67.1 / 71.6 ms.
+      // Per block: F_0, then one launch per level with the update U_l and the next level's factorisation F_{l+1} (k_cq_updfac).
+      static const bool no_fuse = getenv("MPBP_DEBUG_CQ_NOFUSE") != nullptr;
+      hipFuncSetAttribute((const void*)cq::k_cq_updfac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::L2_FAC_TOTAL * 8);
       const int cols16_max = r16i(cols_max);
-      // Two CU-masked streams for the upper levels of the tree (lookahead_streams: sb owns LA_RESERVED CUs, sa the rest):
-      // the factorisation of level l+1 only needs the R factors of level l, so the short chain F_{b+1} -> F_{b+2} -> ...
-      // of the levels whose nodes fit the reserved CUs runs on sb BESIDE the updates U_b, U_{b+1}, ... on sa.  Levels with
-      // more nodes than that fill the chip by themselves and stay on the caller's stream, one after the other.
-      LookAhead* la2 = (coop_err && !getenv("MPBP_DEBUG_CQ_SERIAL")) ? lookahead_streams() : nullptr;
-      auto fac = [&](hipStream_t s, int n, int jb, int level, int slot) {
-        if (fac1) hipLaunchKernelGGL(cq::k_cq_fac, dim3(n, P), dim3(256), cq::L_FAC_TOTAL * 8, s, d_probs, ws_off, jb, level, slot);
-        else hipLaunchKernelGGL(cq::k_cq_fac2, dim3(n, P), dim3(256), cq::L2_FAC_TOTAL * 8, s, d_probs, ws_off, jb, level, slot, 0);
-      };
-      auto upd = [&](hipStream_t s, int cus, int n, int ntl, int jb, int level, int slot) {
-        if (ntl <= 0) return;
-        // tiles per workgroup: one round over the CUs where the level's tiles allow it (one tile per wave and four-wave
-        // workgroups for the small upper levels), else up to four tiles per wave
+      // tiles per workgroup: one tile per wave and four-wave workgroups for the small upper levels; else the number of tile
+      // groups with the fewest (rounds over the CUs) x (time of a workgroup: ~12 us of image load + 6.2 us per tile, measured
+      // with the chip full) - it decides how the last round is filled
+      auto tile_groups = [&](int ntl, int n, int& tpg, int& nthr) {
         const int64_t tiles = (int64_t)ntl * n * P;
-        int tpg = 8, nthr = 512;
-        if (tiles <= 4 * cus) { tpg = 4; nthr = 256; }
-        else {
-          // fewest (rounds over the CUs) x (time of a workgroup: ~12 us of image load + 6.2 us per tile, measured with the
-          // chip full): the number of tile groups decides how the last round is filled
-          double best = 1e30;
-          for (int g = 1; g <= (ntl + 7) / 8; g++) {
-            const int t = (ntl + g - 1) / g;
-            if (t > 64) continue;
-            const int64_t wgs = (int64_t)((ntl + t - 1) / t) * n * P;
-            const double cost = (double)((wgs + cus - 1) / cus) * (12.0 + 6.2 * t);
-            if (cost < best) { best = cost; tpg = t; }
-          }
+        tpg = 8; nthr = 512;
+        if (tiles <= 4 * ncu) { tpg = 4; nthr = 256; return; }
+        double best = 1e30;
+        for (int g = 1; g <= (ntl + 7) / 8; g++) {
+          const int t = (ntl + g - 1) / g;
+          if (t > 64) continue;
+          const int64_t wgs = (int64_t)((ntl + t - 1) / t) * n * P;
+          const double cost = (double)((wgs + ncu - 1) / ncu) * (12.0 + 6.2 * t);
+          if (cost < best) { best = cost; tpg = t; }
         }
-        hipLaunchKernelGGL(cq::k_cq_upd, dim3((ntl + tpg - 1) / tpg, n, P), dim3(nthr), cq::IMG_DOUBLES * 8, s, d_probs, ws_off, jb, level, slot, tpg, 0);
       };
       for (int jb = 0; jb < kmax_max; jb += 64) {
         const int ntl = cols16_max > jb + 64 ? (cols16_max - jb - 64) / 16 : 0;
-        int nl[10], nlev = 0;
-        for (int n = (rows32_max - jb + 255) / 256; nlev < 10; n = (n + 3) / 4) { nl[nlev++] = n; if (n == 1) break; }
-        // b: the last level that stays on the caller's stream
-        int b = nlev - 1;
-        if (la2 && ntl > 0 && nlev <= 9) { b = 0; while (b + 1 < nlev && (int64_t)nl[b + 1] * P > LA_RESERVED) b++; }
+        int nl[12], nlev = 0;
+        for (int n = (rows32_max - jb + 255) / 256; nlev < 12; n = (n + 3) / 4) { nl[nlev++] = n; if (n == 1) break; }
         int slot = 0;
-        for (int level = 0; level <= b; level++) {
-          fac(st, nl[level], jb, level, slot);
-          if (level < b || b == nlev - 1) upd(st, ncu, nl[level], ntl, jb, level, slot);
-          slot += nl[level];
-        }
-        if (b < nlev - 1) {
-          hipEventRecord(la2->e_cq[0], st);
-          hipStreamWaitEvent(la2->sa, la2->e_cq[0], 0); hipStreamWaitEvent(la2->sb, la2->e_cq[0], 0);
-          upd(la2->sa, ncu - LA_RESERVED, nl[b], ntl, jb, b, slot - nl[b]);
-          for (int level = b + 1; level < nlev; level++) {
-            fac(la2->sb, nl[level], jb, level, slot);
-            hipEventRecord(la2->e_cq[level], la2->sb);
-            hipStreamWaitEvent(la2->sa, la2->e_cq[level], 0);
-            upd(la2->sa, ncu - LA_RESERVED, nl[level], ntl, jb, level, slot);
-            slot += nl[level];
+        hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[0], P), dim3(256), cq::L2_FAC_TOTAL * 8, st, d_probs, ws_off, jb, 0, 0, 0);
+        for (int level = 0; level < nlev; level++) {
+          const int n = nl[level];
+          const bool more = level + 1 < nlev;
+          int tpg = 8, nthr = 512;
+          if (ntl > 0) tile_groups(ntl, n, tpg, nthr);
+          const int ntg = ntl > 0 ? (ntl + tpg - 1) / tpg : 0;
+          if (ntl > 0 && more && !no_fuse) {
+            const int64_t wgs = (int64_t)P * nl[level + 1] + (int64_t)P * n * ntg;
+            hipLaunchKernelGGL(cq::k_cq_updfac, dim3((unsigned)wgs), dim3(256), cq::L2_FAC_TOTAL * 8, st, d_probs, P, ws_off, jb, level, slot, n, ntg,
+                               tpg, slot + n, nl[level + 1]);
+          } else {
+            if (ntl > 0) {
+              if (nthr == 256) hipLaunchKernelGGL(cq::k_cq_upd<256>, dim3(ntg, n, P), dim3(256), cq::IMG_DOUBLES * 8, st, d_probs, ws_off, jb, level, slot, tpg, 0);
+              else hipLaunchKernelGGL(cq::k_cq_upd<512>, dim3(ntg, n, P), dim3(512), cq::IMG_DOUBLES * 8, st, d_probs, ws_off, jb, level, slot, tpg, 0);
+            }
+            if (more) hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[level + 1], P), dim3(256), cq::L2_FAC_TOTAL * 8, st, d_probs, ws_off, jb, level + 1, slot + n, 0);
           }
-          hipEventRecord(la2->e_cq[9], la2->sa);
-          hipStreamWaitEvent(st, la2->e_cq[9], 0);
+          slot += n;
         }
       }
       return hipGetLastError() == hipSuccess ? 0 : -2;
