@@ -2,6 +2,7 @@
 // Host responsibilities: compose the per-node tables from the factor primitives (prob_y_partial,
 // reference src/recursive_bp_factor.jl:49-54), unroll CavityTools.cavity into a levelled DAG of `op`s
 // (src/recursive_bp_factor.jl:140), lay trains out in HBM and launch the kernels of kernels.h.
+#include <chrono>
 #include "kernels.h"
 #include "ctx.h"
 #include "v2_engine.h"
@@ -435,7 +436,21 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
 
 }  // namespace
 
+static int launch_engine_impl(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool count_as_orth, float* ms_orth, int* n_orth);
+// MPBP_V2_TIMING=1: wall time of every engine launch (host planning + device, stream drained) on stderr
 static int launch_engine(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool count_as_orth, float* ms_orth, int* n_orth) {
+  static const bool tm = getenv("MPBP_V2_TIMING") != nullptr;
+  if (!tm) return launch_engine_impl(c, pl, trunc, count_as_orth, ms_orth, n_orth);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = launch_engine_impl(c, pl, trunc, count_as_orth, ms_orth, n_orth);
+  (void)hipStreamSynchronize(c->stream);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  bool mir = false; for (const EngProb& P : pl.probs) mir = mir || P.mirror;
+  fprintf(stderr, "[engine launch] nprob=%zu caps=%dx%d->%d ny=%d q=%d small=%d grid=%d mirror=%d cavity=%d  %10.1f ms\n", pl.probs.size(), pl.cap1, pl.cap2,
+          pl.capout, pl.ny, pl.q, (int)pl.small, (int)pl.ext, (int)mir, (int)count_as_orth, ms);
+  return rc;
+}
+static int launch_engine_impl(mpbp_ctx* c, EngLaunchPlan& pl, mpbp_trunc trunc, bool count_as_orth, float* ms_orth, int* n_orth) {
   const int nprob = (int)pl.probs.size();
   if (nprob == 0) return MPBP_OK;
   // sort by decreasing cost (longest first)

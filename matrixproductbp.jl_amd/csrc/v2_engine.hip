@@ -157,12 +157,13 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
   //      the per-problem scratch behind the fixed header (lay.part on: partial products / Grams / W0 of the other form)
   {
     static const bool no_cq = getenv("MPBP_DEBUG_NO_CAQR") != nullptr;
+    static const int cq_min_rows = [] { const char* e = getenv("MPBP_CQ_MIN_ROWS"); return e ? atoi(e) : v2::CH; }();
     bool tall_all = true;
     for (const QrDims& d : dims) tall_all = tall_all && d.rows >= d.cols;
     int64_t slots = 0;
     for (int n = (rows32_max + 255) / 256;; n = (n + 3) / 4) { slots += n; if (n == 1) break; }
     const int64_t ws_off = lay.part;
-    if (!no_cq && !force_tall && aux2 > 0 && tall_all && rows32_max > v2::CH && ws_off + slots * cq::IMG_DOUBLES <= 2 * aux2) {
+    if (!no_cq && !force_tall && aux2 > 0 && tall_all && rows32_max > cq_min_rows && ws_off + slots * cq::IMG_DOUBLES <= 2 * aux2) {
       hipFuncSetAttribute((const void*)cq::k_cq_upd<512>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::IMG_DOUBLES * 8);
       hipFuncSetAttribute((const void*)cq::k_cq_upd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::IMG_DOUBLES * 8);
       hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::L2_FAC_TOTAL * 8);

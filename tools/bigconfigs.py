@@ -19,7 +19,7 @@ if which == "inf":
         t0 = time.time(); M.onebpiter(bp, [0], M.TruncBond(Mb)); st = bp.last_stats
         b = np.array(M.beliefs(bp)[0])
         print(f"infinite k=3 T={T} d={Mb} iter {s}: {time.time()-t0:.2f}s flags nan={st.nan_flag} cap={st.capacity_flag} "
-              f"jac={st.jacobi_not_converged} maxbond={bp.bonds().max()} b[T]={b[-1]} sum-err={np.abs(b.sum(axis=1)-1).max():.1e}", flush=True)
+              f"jac={st.jacobi_not_converged} jacobi sweeps/call={st.jacobi_sweeps / max(1, st.jacobi_calls):.1f} maxbond={bp.bonds().max()} b[T]={b[-1]} sum-err={np.abs(b.sum(axis=1)-1).max():.1e}", flush=True)
 else:
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     Mb = int(sys.argv[3]) if len(sys.argv) > 3 else 40
@@ -32,4 +32,4 @@ else:
         t0 = time.time(); M.onebpiter(bp, np.arange(N, dtype=np.int32), M.TruncBond(Mb)); st = bp.last_stats
         b = np.array(M.beliefs(bp))
         print(f"karate T={T} d={Mb} sweep {s}: {time.time()-t0:.2f}s n_compress={st.n_compress} flags nan={st.nan_flag} cap={st.capacity_flag} "
-              f"jac={st.jacobi_not_converged} maxbond={bp.bonds().max()} belief sum err={np.abs(b.sum(axis=2)-1).max():.2e} min={b.min():.2e}", flush=True)
+              f"jac={st.jacobi_not_converged} jacobi sweeps/call={st.jacobi_sweeps / max(1, st.jacobi_calls):.1f} maxbond={bp.bonds().max()} belief sum err={np.abs(b.sum(axis=2)-1).max():.2e} min={b.min():.2e}", flush=True)
