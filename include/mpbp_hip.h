@@ -134,6 +134,21 @@ int mpbp_set_factor(mpbp_ctx* ctx, int32_t node, int32_t deg, const int32_t* nst
                     const double* prob_y, const double* prob_xy, const double* prob_yy,
                     const double* prob_y0);
 
+/*
+ * Factor of node `node` as a GENERIC `BPFactor` (reference src/bp_core.jl:1-10: only the functor
+ * `w(x_next, x_neighbours, x)` exists, e.g. `GenericGlauberFactor` src/Models/glauber/glauber_bp.jl:1-20, `GenericFactor`
+ * src/test_factors.jl).  The node is then updated by the exhaustive-trace path instead of the recursive one:
+ * `f_bp` (src/bp_core.jl:18-57), `f_bp_dummy_neighbor` (:60-93) and the generic `onebpiter!` (src/mpbp.jl:117-154) -
+ * for every out-neighbour j the product of the other z-1 incoming messages, summed over their joint states with the
+ * transition table, `mpem2 |> compress!(is_orthogonal=:left)`, `normalize!`, stored WITHOUT damping (src/mpbp.jl:131);
+ * the belief from all z messages, compressed before it is marginalised (:145-154).
+ *   w[t][x_next + q (x + q (x_1 + q (x_2 + ... + q x_deg)))] = w_i^t(x_next | x_1 .. x_deg, x)   (neighbours in position
+ *   order, 0-based states; one block if nt == 1, else T+1 blocks; the block of the last time is not read: src/bp_core.jl:41)
+ * Cost and size are exponential in the degree (bond max_bond^(deg-1) before compression): the call to `mpbp_sweep`
+ * fails with MPBP_EUNSUPPORTED if q^3 max_bond^(deg-1) or q^2 max_bond^deg exceeds 2048.  Not available on chains periodic in time.
+ */
+int mpbp_set_generic_factor(mpbp_ctx* ctx, int32_t node, int32_t deg, int32_t nt, const double* w);
+
 /* phi[i][t][x]: double[q][T+1][n_nodes] (x fastest)  - `bp.ϕ`, reference src/mpbp.jl:4 */
 int mpbp_set_phi(mpbp_ctx* ctx, const double* phi);
 /* psi[e][t][x_src][x_dst]: double[q][q][T+1][n_edges] (x_src fastest) - `bp.ψ`, src/mpbp.jl:5 */

@@ -72,6 +72,16 @@ function factor_tables(w::RecursiveBPFactor, q::Int, deg::Int)
     ny, py, pxy, pyy, py0
 end
 
+"Dense transition table of a generic `BPFactor` (src/bp_core.jl:1-10) for `mpbp_set_generic_factor`:
+ `w[x', x, x_1, ..., x_deg]`, first index fastest."
+function generic_table(w::BPFactor, q::Int, deg::Int)
+    tab = zeros(Float64, q, q, ntuple(_ -> q, deg)...)
+    for xs in Iterators.product(ntuple(_ -> 1:q, deg)...), x in 1:q, xn in 1:q
+        tab[xn, x, xs...] = w(xn, collect(xs), x)
+    end
+    vec(tab)
+end
+
 function HIPBackend(bp::MPBP; max_bond::Integer, device::Integer=0)
     g = bp.g; N = nv(g); E = ne(g); T = getT(bp); q = nstates(bp.b[1])
     all(nstates(b) == q for b in bp.b) || error("heterogeneous nstates is not on the device path")
@@ -88,6 +98,12 @@ function HIPBackend(bp::MPBP; max_bond::Integer, device::Integer=0)
         deg = Int(nbr_ptr[i+1] - nbr_ptr[i])
         same = all(w == bp.w[i][1] for w in bp.w[i])
         ts = same ? (1:1) : (1:T+1)
+        if !(eltype(bp.w[i]) <: RecursiveBPFactor)      # generic factor: exhaustive-trace update (src/mpbp.jl:117-154)
+            tab = reduce(vcat, [generic_table(bp.w[i][t], q, deg) for t in ts])
+            check(ccall((:mpbp_set_generic_factor, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float64}),
+                        be.h, i - 1, deg, length(ts), tab), be.h)
+            continue
+        end
         tabs = [factor_tables(bp.w[i][t], q, deg) for t in ts]
         ny = tabs[1][1]
         cat(k) = reduce(vcat, [vec(tb[k]) for tb in tabs])

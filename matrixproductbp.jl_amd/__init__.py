@@ -3,8 +3,8 @@ iterate!/onebpiter! path).  The compute lives in csrc/ (HIP, gfx950) behind the 
 include/mpbp_hip.h; this package is the thin host mirror of the reference's interface."""
 from . import _lib
 from ._lib import MPBPError, build
-from .factors import (DampedFactor, HomogeneousGlauberFactor, IntegerGlauberFactor, PMJGlauberFactor,
-                      RecursiveBPFactor, SIRSFactor, SIS_heterogeneousFactor, SISFactor, glauber_factors)
+from .factors import (BPFactor, DampedFactor, GenericFactor, GenericGlauberFactor, HomogeneousGlauberFactor,
+                      IntegerGlauberFactor, PMJGlauberFactor, RecursiveBPFactor, SIRSFactor, SIS_heterogeneousFactor, SISFactor, glauber_factors)
 from .models import SIS, Glauber, Ising
 from .mpbp import (CB_BP, MPBP, random_message, periodic_mpbp, periodic_mpbp_infinite_graph, is_periodic, autocorrelations, autocovariances, belief_train, beliefs_tu, twovar_marginals, IndexedBiDiGraph, InfiniteBipartiteRegularGraph, InfiniteRegularGraph, TruncBond,
                    TruncBondMax, TruncBondThresh, TruncThresh, beliefs, bethe_free_energy, color_classes,

@@ -36,6 +36,10 @@ struct NodeFactor {
   std::vector<double> prob_y, prob_xy, prob_yy, prob_y0;
   std::vector<int64_t> yy_off;   // offset of block (d1,d2) inside one time block of prob_yy
   int64_t yy_tblock = 0;
+  // generic (non-recursive) factor, mpbp_set_generic_factor: the dense transition table
+  //   gen_w[t][x' + q (x_i + q (x_1 + q (x_2 + ... )))] = w_i^t(x' | x_1 .. x_deg, x_i)     (neighbours in position order)
+  bool generic = false;
+  std::vector<double> gen_w;
 };
 
 // bump allocator over one device arena, regrown on demand between sweeps

@@ -119,6 +119,50 @@ __global__ void prep_kernel(const PrepProb* probs, int L) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// kron: the un-truncated product of incoming messages that the generic (exhaustive-trace) update sums over
+//   A[t][(a_1..a_n),(a_1'..a_n'), y = (x_1..x_n), xi] = prod_k mu_{k->i}[t][a_k, a_k', x_k, xi]
+//   (reference src/bp_core.jl:36-38 / :74-76: `kron` over the neighbours k != j inside the loop over x_{\partial i \ j};
+//   the psi factors and the transition probability are folded into W by the host, so that ctilde_kernel - which computes
+//   B[t][m,n,xi,xj,x'] = sum_y W[t][x',xi,xj,y] A[t][m,n,y,xi] - finishes f_bp exactly as it finishes _f_bp_partial).
+//   First listed neighbour fastest in all three groups (a gauge choice for the bonds, a convention for y shared with W).
+// ------------------------------------------------------------------------------------------------
+constexpr int KRON_MAXK = 8;
+struct KronProb {
+  const double* msg[KRON_MAXK]; const int32_t* mbond[KRON_MAXK]; int64_t mstride;
+  double* out; int32_t* obond; int64_t ostride; double* ologz;
+  int32_t nk, q;
+};
+
+__global__ void kron_kernel(const KronProb* probs, int L) {
+  const KronProb P = probs[blockIdx.y];
+  const int t = blockIdx.x;
+  const int q = P.q, nk = P.nk;
+  int bl[KRON_MAXK], br[KRON_MAXK];
+  int64_t Bl = 1, Br = 1, ny = 1;
+  for (int k = 0; k < nk; k++) { bl[k] = P.mbond[k][t]; br[k] = P.mbond[k][t + 1]; Bl *= bl[k]; Br *= br[k]; ny *= q; }
+  if (threadIdx.x == 0) {
+    P.obond[t] = (int32_t)Bl;
+    if (t == L - 1) { P.obond[L] = (int32_t)Br; *P.ologz = 0.0; }       // messages are stored normalised (z = 1)
+  }
+  double* O = P.out + (int64_t)t * P.ostride;
+  const int64_t tot = Bl * Br * ny * q;
+  for (int64_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+    int64_t r = idx;
+    int64_t m = r % Bl; r /= Bl;
+    int64_t n = r % Br; r /= Br;
+    int64_t y = r % ny; const int xi = (int)(r / ny);
+    double v = 1.0;
+    for (int k = 0; k < nk; k++) {
+      const int a = (int)(m % bl[k]); m /= bl[k];
+      const int b = (int)(n % br[k]); n /= br[k];
+      const int xk = (int)(y % q); y /= q;
+      v *= P.msg[k][(int64_t)t * P.mstride + a + (int64_t)bl[k] * (b + (int64_t)br[k] * (xk + q * xi))];
+    }
+    O[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // ctilde: apply the transition table and embed the MPEM3 as an explicit MPEM2 of doubled bond
 //   B[t][m,n,xi,xj,x'] = sum_y W[t][x',xi,xj,y] A[t][m,n,y,xi]        (src/recursive_bp_factor.jl:79-84)
 //   Ct[t][(m,a),(n,x'),(xi,xj)] = delta(a,xi) B[t][m,n,xi,xj,x']       (exact restatement of the index

@@ -59,12 +59,13 @@ extern "C" int mpbp_create(mpbp_ctx** out, const mpbp_desc* d) {
   if ((e = hipMalloc(&c->d_one, sizeof(double) * 4)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&c->d_ones, sizeof(int32_t) * (c->L + 2))) != hipSuccess) return bail("hipMalloc", e);
   c->ident_n = c->q * c->q;
-  if ((e = hipMalloc(&c->d_ident, sizeof(double) * c->ident_n * c->ident_n)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_ident, sizeof(double) * (c->ident_n * c->ident_n + c->q * c->q))) != hipSuccess) return bail("hipMalloc", e);
   {
     double one[4] = {1.0, 0.0, 0.0, 0.0};
     std::vector<int32_t> ones(c->L + 2, 1);
-    std::vector<double> id((size_t)c->ident_n * c->ident_n, 0.0);
+    std::vector<double> id((size_t)c->ident_n * c->ident_n + (size_t)c->q * c->q, 0.0);
     for (int i = 0; i < c->ident_n; i++) id[i + (size_t)c->ident_n * i] = 1.0;
+    for (int i = 0; i < c->q; i++) id[(size_t)c->ident_n * c->ident_n + i + (size_t)c->q * i] = 1.0;     // q x q identity (generic beliefs)
     hipMemcpy(c->d_one, one, sizeof one, hipMemcpyHostToDevice);
     hipMemcpy(c->d_ones, ones.data(), sizeof(int32_t) * ones.size(), hipMemcpyHostToDevice);
     hipMemcpy(c->d_ident, id.data(), sizeof(double) * id.size(), hipMemcpyHostToDevice);
@@ -142,6 +143,7 @@ extern "C" int mpbp_set_factor(mpbp_ctx* c, int32_t node, int32_t deg, const int
   if (nt != 1 && nt != c->L) return c->fail(MPBP_EINVAL, "nt must be 1 or T+1");
   if (!nstates || !prob_y || !prob_yy || !prob_y0 || (deg > 0 && !prob_xy)) return c->fail(MPBP_EINVAL, "null table");
   NodeFactor& f = c->fac[node];
+  f.generic = false; f.gen_w.clear();
   f.set = true; f.deg = deg; f.nt = nt; f.ny.assign(nstates, nstates + deg + 1);
   for (int l = 0; l <= deg; l++) if (f.ny[l] < 1) return c->fail(MPBP_EINVAL, "nstates must be >= 1");
   const int q = c->q;
@@ -156,6 +158,24 @@ extern "C" int mpbp_set_factor(mpbp_ctx* c, int32_t node, int32_t deg, const int
   f.prob_xy.assign(prob_xy, prob_xy + xy_sz * nt);
   f.prob_yy.assign(prob_yy, prob_yy + off * nt);
   f.prob_y0.assign(prob_y0, prob_y0 + (int64_t)f.ny[0] * q * nt);
+  c->tables_dirty = true;
+  return MPBP_OK;
+}
+
+extern "C" int mpbp_set_generic_factor(mpbp_ctx* c, int32_t node, int32_t deg, int32_t nt, const double* w) {
+  if (!c) return MPBP_EINVAL;
+  if (node < 0 || node >= c->N) return c->fail(MPBP_EINVAL, "node %d out of range", node);
+  if (deg != c->nbr_ptr[node + 1] - c->nbr_ptr[node]) return c->fail(MPBP_EINVAL, "node %d: degree %d does not match the graph (%d)", node, deg, c->nbr_ptr[node + 1] - c->nbr_ptr[node]);
+  if (nt != 1 && nt != c->L) return c->fail(MPBP_EINVAL, "nt must be 1 or T+1");
+  if (!w) return c->fail(MPBP_EINVAL, "null table");
+  if (c->periodic) return c->fail(MPBP_EUNSUPPORTED, "generic factors on chains periodic in time are not supported on the device");
+  if (deg > KRON_MAXK) return c->fail(MPBP_EUNSUPPORTED, "generic factor of degree %d: the exhaustive update enumerates q^degree neighbour states, at most degree %d is supported", deg, KRON_MAXK);
+  int64_t sz = (int64_t)c->q * c->q;
+  for (int k = 0; k < deg; k++) { sz *= c->q; if (sz > ((int64_t)1 << 26)) return c->fail(MPBP_EUNSUPPORTED, "generic factor table of node %d is too large", node); }
+  NodeFactor& f = c->fac[node];
+  f = NodeFactor{};
+  f.set = true; f.generic = true; f.deg = deg; f.nt = nt;
+  f.gen_w.assign(w, w + sz * nt);
   c->tables_dirty = true;
   return MPBP_OK;
 }
@@ -272,6 +292,46 @@ static int build_tables(mpbp_ctx* c) {
   for (int i = 0; i < N; i++) {
     const NodeFactor& f = c->fac[i];
     const int z = f.deg;
+    if (f.generic) {
+      // Generic factor (reference src/bp_core.jl:18-57, :60-93): W[t][x', x, xj, y] with y = the joint state of the other
+      // neighbours (position order, first fastest) = w(x' | x_1..x_z, x) phi(x) prod_{k != j} psi_{i->k}(x, x_k); the last
+      // site carries phi and the psi only (bp_core.jl:41-45).  The belief table sums over all z neighbours (qj = 1).
+      int64_t qz = 1;
+      for (int k = 0; k < z; k++) qz *= q;
+      auto GW = [&](int t, int xn, int x, int64_t cfg) { return f.gen_w[(f.nt == 1 ? 0 : (size_t)t * q * q * qz) + xn + q * (x + (size_t)q * cfg)]; };
+      for (int j = 0; j < z; j++) {
+        const int p = c->nbr_ptr[i] + j;
+        const int64_t nyo = qz / q;
+        std::vector<double> w((size_t)L * q * q * q * nyo);
+        for (int t = 0; t < L; t++)
+          for (int64_t y = 0; y < nyo; y++)
+            for (int xj = 0; xj < q; xj++) {
+              // full configuration: the others in order, xj inserted at position j
+              int64_t cfg = 0, mul = 1, yy = y; int xs[KRON_MAXK + 1];
+              for (int k = 0; k < z; k++) { xs[k] = (k == j) ? xj : (int)(yy % q); if (k != j) yy /= q; cfg += mul * xs[k]; mul *= q; }
+              for (int x = 0; x < q; x++) {
+                double ps = PHI(i, t, x);
+                for (int k = 0; k < z; k++) if (k != j) ps *= PSI(c->out_edge[c->nbr_ptr[i] + k], t, x, xs[k]);
+                for (int xn = 0; xn < q; xn++)
+                  w[(size_t)t * q * q * q * nyo + xn + q * (x + q * (xj + (size_t)q * y))] = (t == L - 1) ? ps : ps * GW(t, xn, x, cfg);
+              }
+            }
+        c->wmsg_off[p] = ts.add(w);
+      }
+      std::vector<double> w((size_t)L * q * q * qz);
+      for (int t = 0; t < L; t++)
+        for (int64_t y = 0; y < qz; y++) {
+          int64_t yy = y; int xs[KRON_MAXK + 1];
+          for (int k = 0; k < z; k++) { xs[k] = (int)(yy % q); yy /= q; }
+          for (int x = 0; x < q; x++) {
+            double ps = PHI(i, t, x);
+            for (int k = 0; k < z; k++) ps *= PSI(c->out_edge[c->nbr_ptr[i] + k], t, x, xs[k]);
+            for (int xn = 0; xn < q; xn++) w[(size_t)t * q * q * qz + xn + q * (x + (size_t)q * y)] = (t == L - 1) ? ps : ps * GW(t, xn, x, y);
+          }
+        }
+      c->wbel_off[i] = ts.add(w);
+      continue;
+    }
     const int nyz = f.ny[z];
     auto PY = [&](int t, int xn, int x, int y) { return f.prob_y[(f.nt == 1 ? 0 : (size_t)t * q * q * nyz) + xn + q * (x + (size_t)q * y)]; };
     const int ny1 = z > 0 ? f.ny[1] : 1;
@@ -410,8 +470,10 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   cfg.lds_qr = ltake(pl.small ? v64::wg::QR_LDS_DOUBLES : v512::wg::QR_LDS_DOUBLES);
   cfg.lds_misc = ltake(32 + nmax + (nmax + 1) / 2 + 4);
   cfg.lds_rdim = ltake((L + 2 + 1) / 2 + 2);
-  // 512-thread variant: one workgroup per CU, 150 KiB; single-wave variant: four per CU
-  const int64_t budget = pl.small ? (38 * 1024) / 8 : (150 * 1024) / 8;
+  // 512-thread variant: one workgroup per CU, 158 of the CU's 160 KiB (the kernel has no static LDS; 150 KiB until round 3:
+  // the 257 x 64 Jacobi of a product with the bond-1 init train at bond 64 - configs[4] - needs 156 KiB with the fixed
+  // part and ran from HBM, 2 - 5 ms per time step); single-wave variant: four per CU
+  const int64_t budget = pl.small ? (38 * 1024) / 8 : (158 * 1024) / 8;
   const int64_t base = l;
   const int64_t coresE = ((nA1 + 3) & ~3) + ((nA2 + 3) & ~3) + ((nE + 3) & ~3);
   // JA only (V is not accumulated): [Rr | 1] x min(r1, Rr) with Rr <= nmax, r1 <= Bmax
@@ -599,13 +661,16 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
   float ms_orth = 0.f; int n_orth = 0;
 
   // ---------------------------------------------------------------- plan: trains, ops, levels
-  struct TrainSpec { int cap, ny, qphys; int d; int level; int64_t tab_off; bool is_init; int node; };
+  struct TrainSpec { int cap, ny, qphys; int d; int level; int64_t tab_off; bool is_init; int node; int kron_skip = -2; };   // kron_skip >= -1: product of the node's in-messages except that position (generic factors)
   std::vector<TrainSpec> specs;     // scratch trains to allocate
   std::vector<DevTrain> tr;         // filled after allocation (same indexing)
   auto new_train = [&](int capv, int ny, int qphys, int d, int level) {
     specs.push_back({capv, ny, qphys, d, level, 0, false, -1});
     return (int)specs.size() - 1;
   };
+  // generic factors (mpbp_set_generic_factor): cap^n bond and q^n joint neighbour states of a product of n messages
+  auto ipow = [](int64_t b, int n) { int64_t r = 1; for (int k = 0; k < n; k++) { r *= b; if (r > ((int64_t)1 << 40)) break; } return r; };
+  bool any_generic = false;
   std::vector<OpRec> ops;
   struct NodePlan { int node; std::vector<int> src, dest; int full; int init; };
   std::vector<NodePlan> plans(n_nodes);
@@ -616,6 +681,26 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
     const int z = f.deg;
     NodePlan& P = plans[k];
     P.node = i;
+    if (f.generic) {
+      // Exhaustive-trace update (reference src/bp_core.jl:18-93, src/mpbp.jl:117-154): no cavity; the message to neighbour j
+      // sums over the joint states of the other z-1 neighbours, the belief over all z.  The mirrored engine compresses the
+      // embeddings in one 512-thread workgroup each, whose register panel holds 2048 rows of Y_t.
+      any_generic = true;
+      const int64_t bm = ipow(cap, z - 1) * c->ct_factor(), bb = ipow(cap, z) * c->ct_factor();
+      if (z > 0 && (bm * q * q > 2048 || bb * q > 2048))
+        return c->fail(MPBP_EUNSUPPORTED, "node %d: generic factor of degree %d with max_bond %d needs product bonds %lld / %lld (limit: q^2 x bond <= 2048 rows); "
+                       "the exhaustive update is exponential in the degree - use a RecursiveBPFactor model, a smaller max_bond or fewer neighbours",
+                       i, z, cap, (long long)bm, (long long)bb);
+      P.init = -1;
+      P.dest.assign(z, -1);
+      for (int j = 0; j < z; j++) {
+        P.dest[j] = new_train((int)ipow(cap, z - 1), (int)ipow(q, z - 1), q, 0, 0);
+        specs[P.dest[j]].node = i; specs[P.dest[j]].kron_skip = j;
+      }
+      P.full = new_train((int)ipow(cap, z), (int)ipow(q, z), q, 0, 0);
+      specs[P.full].node = i; specs[P.full].kron_skip = -1;
+      continue;
+    }
     P.init = new_train(1, f.ny[0], q, 0, 0);
     specs[P.init].is_init = true; specs[P.init].node = i;
     for (int j = 0; j < z; j++) P.src.push_back(new_train(cap, f.ny[1], q, 1, 0));
@@ -641,18 +726,20 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
     }
   }
   // finalisation trains: ctilde (bond 2*cap... = q*cap), engine output (message), belief ctilde
-  struct FinRec { int k, j, p, src, ct, out; int nrm = -1, sum = -1, out2 = -1, occ = 0; };
+  struct FinRec { int k, j, p, src, ct, out; int nrm = -1, sum = -1, out2 = -1, occ = 0; bool gen = false; };
   std::vector<FinRec> fins; std::vector<FinRec> bels;
   const int capct = c->ct_factor() * cap;
   for (int k = 0; k < n_nodes; k++) {
     NodePlan& P = plans[k];
     const int i = P.node; const int z = c->fac[i].deg;
+    const bool gen = c->fac[i].generic;
     for (int j = 0; j < z; j++) {
       const int p = c->nbr_ptr[i] + j;
-      const int ct = new_train(capct, q * q, 1, 0, 0);      // explicit cores: ny = q*qj, engine q = 1
+      const int ct = new_train(gen ? c->ct_factor() * specs[P.dest[j]].cap : capct, q * q, 1, 0, 0);      // explicit cores: ny = q*qj, engine q = 1
       const int out = new_train(cap, q * q, 1, 0, 0);
       FinRec fr{k, j, p, P.dest[j], ct, out};
-      if (damp > 0.0) {
+      fr.gen = gen;
+      if (damp > 0.0 && !gen) {        // the generic update assigns the new message without damping (reference src/mpbp.jl:131)
         fr.nrm = new_train(cap, q * q, 1, 0, 0);            // normalised new message
         fr.sum = new_train(2 * cap, q * q, 1, 0, 0);        // new + damp/(1-damp) * old  (direct sum)
         fr.out2 = new_train(cap, q * q, 1, 0, 0);           // compressed again
@@ -660,8 +747,11 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
       }
       fins.push_back(fr);
     }
-    const int ctb = new_train(capct, q, 1, 0, 0);           // belief: qj = 1
-    bels.push_back({k, -1, -1, P.full, ctb, -1});
+    const int ctb = new_train(gen ? c->ct_factor() * specs[P.full].cap : capct, q, 1, 0, 0);           // belief: qj = 1
+    FinRec br{k, -1, -1, P.full, ctb, -1};
+    br.gen = gen;
+    if (gen) br.out = new_train(cap, q, 1, 0, 0);           // the generic belief is compressed before it is marginalised (src/mpbp.jl:145-154)
+    bels.push_back(br);
   }
   // ---------------------------------------------------------------- allocate the arena
   c->arena.reset();
@@ -715,6 +805,7 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
     std::vector<PrepProb> pp;
     for (int k = 0; k < n_nodes; k++) {
       const int i = plans[k].node; const NodeFactor& f = c->fac[i];
+      if (f.generic) continue;
       for (int j = 0; j < f.deg; j++) {
         const int p = c->nbr_ptr[i] + j;
         const int ein = c->in_edge[p];
@@ -734,6 +825,29 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+  }
+  // ---------------------------------------------------------------- generic factors: products of the in-messages
+  if (any_generic) {
+    std::vector<KronProb> kp;
+    for (size_t s2 = 0; s2 < specs.size(); s2++) {
+      if (specs[s2].kron_skip < -1) continue;
+      const int i = specs[s2].node;
+      KronProb K{};
+      K.nk = 0; K.q = q; K.mstride = c->core_stride;
+      for (int j = 0; j < c->fac[i].deg; j++) {
+        if (j == specs[s2].kron_skip) continue;
+        const int ein = c->in_edge[c->nbr_ptr[i] + j];
+        K.msg[K.nk] = c->read_slot_cores(ein); K.mbond[K.nk] = c->read_slot_bonds(ein); K.nk++;
+      }
+      K.out = tr[s2].cores; K.obond = tr[s2].bonds; K.ostride = tr[s2].stride; K.ologz = tr[s2].logz;
+      kp.push_back(K);
+    }
+    int rc = ensure_arena(c, c->scratch, sizeof(KronProb) * kp.size() + 4096);
+    if (rc != MPBP_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->scratch.base, kp.data(), sizeof(KronProb) * kp.size(), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(kron_kernel, dim3(L, (unsigned)kp.size()), dim3(256), 0, c->stream, (const KronProb*)c->scratch.base, L);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   // ---------------------------------------------------------------- cavity ops
   // The single-wave problems go level by level.  The 512-thread problems are packed into launches by readiness
@@ -845,19 +959,31 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
     // engine (mirror): mpem2 |> compress!(:left) |> normalize_eachmatrix!
     EngLaunchPlan pl; pl.q = 1; pl.capout = cap; pl.cap1 = capct; pl.cap2 = 1; pl.ny1 = q * q; pl.ny2 = 1; pl.ny = q * q;
     pl.small = small_problem(capct, q * q, 1);
-    for (const FinRec& fr : fins) {
+    // generic factors: embeddings of bond q cap^(z-1) (messages, ny = q qj) and q cap^z (beliefs, ny = q), own launches
+    EngLaunchPlan plg = pl, plgb = pl;
+    plg.cap1 = 1; plgb.cap1 = 1; plgb.ny1 = q; plgb.ny = q;
+    auto mirror_problem = [&](EngLaunchPlan& plan, const FinRec& fr, int nyv, const double* ident) {
       const DevTrain &ct = tr[fr.ct], &out = tr[fr.out];
       EngProb P{};
-      P.A1 = ct.cores; P.bond1 = ct.bonds; P.stride1 = ct.stride; P.ny1 = q * q;
+      P.A1 = ct.cores; P.bond1 = ct.bonds; P.stride1 = ct.stride; P.ny1 = nyv;
       P.A2 = c->d_one; P.bond2 = c->d_ones; P.stride2 = 0; P.ny2 = 1;
       P.logz1 = ct.logz; P.logz2 = nullptr;
-      P.pyy = c->d_ident; P.pyy_tstride = 0;
-      P.ny = q * q; P.q = 1; P.mirror = 1; P.cap_out = cap;
+      P.pyy = ident; P.pyy_tstride = 0;
+      P.ny = nyv; P.q = 1; P.mirror = 1; P.cap_out = cap;
       P.out = out.cores; P.obond = out.bonds; P.ostride = out.stride; P.ologz = out.logz;
-      pl.probs.push_back(P); pl.cost.push_back(1.0);
-    }
+      plan.probs.push_back(P); plan.cost.push_back((double)ct.cap);
+      plan.cap1 = std::max(plan.cap1, ct.cap);
+    };
+    for (const FinRec& fr : fins) mirror_problem(fr.gen ? plg : pl, fr, q * q, c->d_ident);
+    for (const FinRec& fr : bels) if (fr.gen) mirror_problem(plgb, fr, q, c->d_ident + (size_t)c->ident_n * c->ident_n);
     int rc = launch_engine(c, pl, trunc, false, &ms_orth, &n_orth);
     if (rc != MPBP_OK) return rc;
+    for (EngLaunchPlan* pg : {&plg, &plgb}) {
+      if (pg->probs.empty()) continue;
+      pg->small = small_problem(pg->cap1, pg->ny, 1);
+      rc = launch_engine(c, *pg, trunc, false, &ms_orth, &n_orth);
+      if (rc != MPBP_OK) return rc;
+    }
     // env: normalize! the messages into the slab (damp = 0) or into a temporary (damp > 0);
     //      beliefs marginals + log z_i
     std::vector<EnvProb> eps;
@@ -872,7 +998,7 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
       const DevTrain& out = tr[fr.out];
       EnvProb P{};
       P.in = out.cores; P.ibond = out.bonds; P.istride = out.stride; P.ilogz = out.logz; P.p = q * q;
-      if (damp > 0.0) { const DevTrain& nm = tr[fr.nrm]; P.dst = nm.cores; P.dbond = nm.bonds; P.dstride = nm.stride; }
+      if (damp > 0.0 && !fr.gen) { const DevTrain& nm = tr[fr.nrm]; P.dst = nm.cores; P.dbond = nm.bonds; P.dstride = nm.stride; }
       else { P.dst = last ? c->slot_cores(eo) : nullptr; P.dbond = last ? c->slot_bonds(eo) : nullptr; P.dstride = c->core_stride; }
       P.marg = nullptr; P.logz_out = c->d_logz_pos + fr.p; P.bmax = cap;
       rv_off.push_back(rv_doubles); rv_doubles += (size_t)(L + 1) * cap;
@@ -880,12 +1006,12 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
     }
     for (const FinRec& fr : bels) {
       const int i = plans[fr.k].node;
-      const DevTrain& ct = tr[fr.ct];
+      const DevTrain& ct = fr.gen ? tr[fr.out] : tr[fr.ct];
       EnvProb P{};
       P.in = ct.cores; P.ibond = ct.bonds; P.istride = ct.stride; P.ilogz = ct.logz; P.p = q;
       P.dst = c->d_btrain ? c->d_btrain + (int64_t)i * c->bt_slot : nullptr;
       P.dbond = c->d_btrain ? c->d_bbond + (int64_t)i * (L + 1) : nullptr; P.dstride = c->bt_stride;
-      P.marg = c->d_beliefs + (size_t)q * L * i; P.logz_out = c->d_logz_node + i; P.bmax = capct;
+      P.marg = c->d_beliefs + (size_t)q * L * i; P.logz_out = c->d_logz_node + i; P.bmax = fr.gen ? cap : capct;
       rv_off.push_back(rv_doubles); rv_doubles += (size_t)(L + 1) * capct;
       eps.push_back(P);
     }
@@ -907,13 +1033,13 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
     // ---- damping (reference src/recursive_bp_factor.jl:172-176): mu = compress!(new + damp/(1-damp) old), normalize!
     if (damp > 0.0) {
       int maxocc = 0;
-      for (const FinRec& fr : fins) maxocc = std::max(maxocc, fr.occ);
+      for (const FinRec& fr : fins) if (!fr.gen) maxocc = std::max(maxocc, fr.occ);
       for (int round = 0; round <= maxocc; round++) {      // aliased out-edges compound in the reference's loop order
         std::vector<ComposeProb> cps2; EngLaunchPlan pl2; std::vector<EnvProb> ev2; std::vector<size_t> off2; size_t rvd2 = 0;
         pl2.q = 1; pl2.capout = cap; pl2.cap1 = 2 * cap; pl2.cap2 = 1; pl2.ny1 = q * q; pl2.ny2 = 1; pl2.ny = q * q;
         pl2.small = small_problem(2 * cap, q * q, 1);
         for (const FinRec& fr : fins) {
-          if (fr.occ != round) continue;
+          if (fr.occ != round || fr.gen) continue;
           const int eo = c->out_edge[fr.p];
           const DevTrain &nm = tr[fr.nrm], &sm = tr[fr.sum], &o2 = tr[fr.out2];
           ComposeProb CP{};

@@ -17,7 +17,29 @@ def potts2spin(x):
     return 3 - 2 * x
 
 
-class RecursiveBPFactor:
+class BPFactor:
+    """src/bp_core.jl:1-10: a factor only has to be callable as `w(x_next, x_neighbours, x)` (1-based states).  A factor
+    that is not a `RecursiveBPFactor` is updated by the exhaustive-trace path (`f_bp`, src/bp_core.jl:18-93): the host
+    evaluates the functor into the dense table that `mpbp_set_generic_factor` (include/mpbp_hip.h) takes."""
+
+    def __call__(self, xnext, xnbrs, xi):
+        raise NotImplementedError("Not implemented")
+
+    def key(self):
+        return (type(self).__name__, id(self))
+
+    def generic_table(self, deg: int, q: int):
+        """w[x_next + q (x + q (x_1 + q (x_2 + ...)))], 0-based, first index fastest."""
+        tab = np.zeros((q, q) + (q,) * deg)
+        for cfg in np.ndindex(*((q,) * deg)):
+            xs = [int(v) + 1 for v in cfg]
+            for x in range(q):
+                for xn in range(q):
+                    tab[(xn, x) + tuple(cfg)] = self(xn + 1, xs, x + 1)
+        return tab.ravel(order="F")
+
+
+class RecursiveBPFactor(BPFactor):
     """src/recursive_bp_factor.jl:6-27"""
 
     def nstates(self, l: int) -> int:
@@ -280,7 +302,31 @@ def glauber_factors(A, J, h, beta, T):
         elif all(float(v).is_integer() for v in Ji):
             w = IntegerGlauberFactor([int(v) for v in Ji], h[i], beta)
         else:
-            raise NotImplementedError("GenericGlauberFactor (exhaustive-trace update, reference bp_core.jl:18-57) "
-                                      "is not on the device path")
+            w = GenericGlauberFactor(Ji, h[i], beta)
         out.append([w] * (T + 1))
     return out
+
+
+class GenericGlauberFactor(BPFactor):
+    """src/Models/glauber/glauber_bp.jl:1-20: arbitrary real couplings, no recursive structure."""
+
+    def __init__(self, J, h, beta):
+        self.betaJ = [float(j) * beta for j in J]
+        self.betah = float(h) * beta
+
+    def __call__(self, xnext, xnbrs, xi):
+        assert len(xnbrs) == len(self.betaJ)
+        hji = sum(J * potts2spin(xj) for xj, J in zip(xnbrs, self.betaJ))
+        E = -potts2spin(xnext) * (hji + self.betah)
+        return 1.0 / (1.0 + np.exp(2.0 * E))
+
+
+class GenericFactor(BPFactor):
+    """src/test_factors.jl:41-45: wraps any factor and hides its recursive structure, which forces the
+    exhaustive-trace update (used by the reference's tests to compare the two paths)."""
+
+    def __init__(self, w):
+        self.w = w
+
+    def __call__(self, xnext, xnbrs, xi):
+        return self.w(xnext, xnbrs, xi)

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import MPBPError, Stats, Trunc
-from .factors import RecursiveBPFactor
+from .factors import BPFactor, RecursiveBPFactor
 
 __all__ = ["IndexedBiDiGraph", "InfiniteRegularGraph", "InfiniteBipartiteRegularGraph", "MPBP", "mpbp",
            "mpbp_infinite_graph", "mpbp_infinite_bipartite_graph", "iterate", "onebpiter", "CB_BP", "beliefs",
@@ -216,10 +216,13 @@ class MPBP:
             raise MPBPError(-4, "heterogeneous q is not supported on the device path")
         self.g, self.w, self.q, self.T = g, w, qs.pop(), int(T)
         for i in range(N):
-            for wt in w[i]:
-                if not isinstance(wt, RecursiveBPFactor):
-                    raise MPBPError(-4, "only RecursiveBPFactor models run on the device path "
-                                        "(generic exhaustive-trace update: reference src/bp_core.jl:18-57)")
+            # dispatch on the factor type as src/mpbp.jl:191 does (eltype(bp.w[i])): recursive or generic per node
+            if not all(isinstance(wt, BPFactor) for wt in w[i]):
+                raise MPBPError(-4, "factors must be BPFactor instances (callable as w(x_next, x_neighbours, x))")
+            if len({isinstance(wt, RecursiveBPFactor) for wt in w[i]}) != 1:
+                raise MPBPError(-4, f"node {i}: recursive and generic factors cannot be mixed along one node's chain")
+            if periodic and not isinstance(w[i][0], RecursiveBPFactor):
+                raise MPBPError(-4, "generic factors on chains periodic in time are not supported on the device path")
         self.max_bond = int(max_bond) if max_bond is not None else 16
         self.phi = np.zeros((self.q, T + 1, N))
         self.psi = np.zeros((self.q, self.q, T + 1, E))
@@ -274,6 +277,12 @@ class MPBP:
             const = all(wt is wi[0] or wt.key() == wi[0].key() for wt in wi)
             ws = [wi[0]] if const else list(wi)
             k = (tuple(wt.key() for wt in ws), deg)
+            if not isinstance(wi[0], RecursiveBPFactor):
+                # generic BPFactor: exhaustive-trace update (src/bp_core.jl:18-93) from the dense transition table
+                if k not in cache:
+                    cache[k] = np.ascontiguousarray(np.concatenate([wt.generic_table(deg, q) for wt in ws]))
+                _lib.check(L.mpbp_set_generic_factor(h, i, deg, len(ws), _dp(cache[k])), h)
+                continue
             if k not in cache:
                 tabs = [wt.tables(deg, q) for wt in ws]
                 ny = tabs[0][0]

@@ -1008,3 +1008,93 @@ def test_baseline_config0_glauber_3node_path_exact_gpu():
         p, Z = exact_prob(obp)
     assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-8
     assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-8
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# generic (exhaustive-trace) factors on the device: f_bp / f_bp_dummy_neighbor (reference src/bp_core.jl:18-93) and the
+# generic onebpiter! (src/mpbp.jl:117-154) through mpbp_set_generic_factor
+# ------------------------------------------------------------------------------------------------------------------
+def test_generic_factor_equals_recursive_and_enumeration_sis_tree_gpu():
+    """reference test/sis_small_tree.jl:68-83: `GenericFactor.(w)` forces the exhaustive-trace update; beliefs and pair
+    beliefs must equal the recursive path's - and, on a tree, brute-force enumeration."""
+    A, lam, rho, alpha, phi, T = _sis_star_inputs()
+    tr = M.TruncBondMax(4)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), [[M.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, 2, T, phi=phi, max_bond=4)
+    M.iterate(bp, maxiter=10, svd_trunc=tr, schedule="sequential")
+    wg = [[M.GenericFactor(M.SISFactor(lam, rho, alpha)) for _ in range(T + 1)] for _ in range(4)]
+    bpg = M.mpbp(M.IndexedBiDiGraph(A), wg, 2, T, phi=phi, max_bond=4)
+    M.iterate(bpg, maxiter=10, svd_trunc=M.TruncBondMax(4), schedule="sequential")
+    assert _rel(_flat(M.beliefs(bpg)), _flat(M.beliefs(bp))) < 1e-9
+    pbg, lzg = M.pair_beliefs(bpg)
+    pb, lz = M.pair_beliefs(bp)
+    assert _rel(_flat(pbg), _flat(pb)) < 1e-9
+    assert abs(M.bethe_free_energy(bpg) - M.bethe_free_energy(bp)) < 1e-9
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho, alpha)] * (T + 1)] * 4, [2] * 4, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bpg)), _flat(exact_marginals(obp, p))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bpg)) - Z) / Z < 1e-9
+
+
+def test_generic_glauber_factor_real_couplings_tree_exact_gpu():
+    """reference test/glauber_pmJ_small_tree.jl:64-86 with couplings that no recursive factor type covers
+    (`glauber_factors` then picks `GenericGlauberFactor`, src/Models/glauber/glauber_bp.jl:121-142): exact on a tree,
+    Z, marginals and autocorrelations against enumeration; time-dependent fields through phi."""
+    T = 3
+    J = np.array([[0, 0.3, 0, 0], [0.3, 0, -0.7, 1.1], [0, -0.7, 0, 0], [0, 1.1, 0, 0]], float)
+    rng = np.random.default_rng(5)
+    h = rng.standard_normal(4)
+    phi = [[np.array([0.6, 0.4]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(4)]
+    phi[2][T] = np.array([0.0, 1.0])
+    w = M.glauber_factors(J != 0, J, h, 1.0, T)
+    assert all(isinstance(wi[0], M.GenericGlauberFactor) for wi in w)
+    bp = M.mpbp(M.IndexedBiDiGraph(J != 0), w, 2, T, phi=phi, max_bond=8)
+    M.iterate(bp, maxiter=10, svd_trunc=M.TruncThresh(0.0), schedule="colored")
+    ow = OF.glauber_factors(J != 0, J, h, 1.0, T)
+    assert all(isinstance(wi[0], OF.GenericGlauberFactor) for wi in ow)
+    obp = O.mpbp(O.IndexedBiDiGraph(J != 0), ow, [2] * 4, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+    pb, _ = M.pair_beliefs(bp)
+    assert _rel(_flat(pb), _flat(exact_pair_marginals(obp, p))) < 1e-9
+
+
+def test_generic_factor_loopy_binding_truncation_matches_oracle_gpu():
+    """The generic update under a BINDING cap on a loopy graph, sweep by sweep against the oracle's `onebpiter_generic`
+    (src/mpbp.jl:117-154: the belief is compressed before it is marginalised, messages are stored without damping), with
+    generic and recursive nodes mixed in one graph (dispatch per node, src/mpbp.jl:191)."""
+    N, T, Mb = 8, 4, 4
+    lam, rho, gam = 0.2, 0.1, 0.15
+    A, phi = _loopy(N, T, lam, rho, gam, seed=3)
+    gen = [i % 2 == 0 for i in range(N)]
+    w = [[(M.GenericFactor(M.SISFactor(lam, rho)) if gen[i] else M.SISFactor(lam, rho)) for _ in range(T + 1)] for i in range(N)]
+    ow = [[(OF.GenericFactor(OF.SISFactor(lam, rho)) if gen[i] else OF.SISFactor(lam, rho)) for _ in range(T + 1)] for i in range(N)]
+    bp = M.mpbp(M.IndexedBiDiGraph(A), w, 2, T, phi=phi, max_bond=Mb)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), ow, [2] * N, T, phi=phi)
+    for s in range(3):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(Mb), tol=0.0, damp=0.2)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(Mb), tol=0.0, shuffle_nodes=False, jacobi=True, damp=0.2)
+        assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < RTOL, f"sweep {s}"
+        f = _fnodes(bp)
+        assert np.abs(f - obp.f).max() < RTOL * max(1.0, np.abs(obp.f).max()), f"sweep {s}"
+    pb, lz = M.pair_beliefs(bp)
+    opb, olz = O.pair_beliefs(obp)
+    assert _rel(_flat(pb), _flat(opb)) < RTOL
+    assert (bp.bonds() <= Mb).all()
+    assert np.array_equal(bp.bonds(), np.array([m.bonds for m in obp.mu]))
+    assert bp.last_stats.nan_flag == 0 and bp.last_stats.capacity_flag == 0
+
+
+def test_generic_factor_limits_are_reported_not_aborted():
+    """The exhaustive update is exponential in the degree: a product bond beyond what one workgroup's panel holds is refused
+    with MPBP_EUNSUPPORTED at the sweep, and a generic factor on a chain periodic in time at construction."""
+    A, lam, rho, alpha, phi, T = _sis_star_inputs()
+    wg = [[M.GenericFactor(M.SISFactor(lam, rho, alpha)) for _ in range(T + 1)] for _ in range(4)]
+    bp = M.mpbp(M.IndexedBiDiGraph(A), wg, 2, T, phi=phi, max_bond=16)      # hub: 2 x 16^3 x 2 rows
+    with pytest.raises(M.MPBPError) as ei:
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(16))
+    assert "generic factor" in str(ei.value)
+    with pytest.raises(M.MPBPError):
+        M.periodic_mpbp(M.IndexedBiDiGraph(A), wg, 2, T, phi=phi, max_bond=4)
