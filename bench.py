@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--bond", type=int, default=0, help="override the bond cap")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="with one process: run only rank 0's node block of a K-way sharding (what one GPU of K does per sweep)")
+    ap.add_argument("--shard-index", type=int, default=0, help="with --shard-of K: which rank's node block to run (default 0)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="heavy ops timed by the CPU baseline (>= host cores)")
     ap.add_argument("--saturate", action="store_true",
                     help="start from random normalised messages at the saturated bond profile on the in-edges of the owned "
@@ -338,7 +339,9 @@ def main():
         bonds_t = torch.zeros(nslots, T + 2, dtype=torch.int32, device=dev)
         bp = M.mpbp(g, facs, 2, T, phi=phi, max_bond=Mb, device=local, slot_of_edge=slot,
                     n_slots=nslots, ext_cores=cores_t.data_ptr(), ext_bonds=bonds_t.data_ptr())
-        lo, hi = shards[rank if (shardable and world > 1) else 0]
+        if not (0 <= args.shard_index < len(shards)):
+            raise SystemExit(f"--shard-index {args.shard_index} out of range for {len(shards)} shards")
+        lo, hi = shards[rank if (shardable and world > 1) else (args.shard_index if (world == 1 and args.shard_of > 1 and shardable) else 0)]
     else:
         phi1 = [np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)]
         bp = M.mpbp_infinite_graph(3, [M.SISFactor(lam, rho)] * (T + 1), 2, phi1, max_bond=Mb, device=local)
@@ -346,7 +349,7 @@ def main():
         cores_t = bonds_t = None
     exchange = shardable and world > 1
     if args.saturate and A is not None:
-        rng = np.random.default_rng(1234 + rank)
+        rng = np.random.default_rng(1234 + rank + args.shard_index)
         msgs = [None] * E
         for i in range(lo, hi):
             for p_ in range(int(ptr[i]), int(ptr[i + 1])):
@@ -477,7 +480,7 @@ def main():
         elif replicas:
             par = f"{world} independent replicas (this config does not shard by node)"
         elif world == 1 and args.shard_of > 1 and shardable:
-            par = f"rank 0's node block [{lo},{hi}) of a {args.shard_of}-way sharding, on 1 GPU"
+            par = f"rank {args.shard_index}'s node block [{lo},{hi}) of a {args.shard_of}-way sharding, on 1 GPU"
         out = {"metric": metric,
                "value": value, "unit": "edge-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "s_per_sweep": ms_per_step / 1e3, "higher_is_better": True,
