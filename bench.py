@@ -321,16 +321,15 @@ def main():
         nshard = world if shardable else 1
         if world == 1 and args.shard_of > 1 and shardable:
             nshard = args.shard_of
-        # shards are cut by predicted time: executed flops at the measured rate + the part of a hub's dependency chain that
-        # runs alone on the chip (dist.node_times)
+        # shards are cut by predicted time: the executed flops of a rank's nodes at the measured rate + the part of its deepest
+        # node's dependency chain that runs alone on the chip (dist.node_times / shard_nodes_by_time)
         work_s, tail_s = D.node_times(ptr, 2, Mb, T, nstates=nstates)
-        cost = work_s + tail_s
         if shardable and world > 1:
-            slot, S, shards = D.slot_map(ptr, oute, E, world, cost)
+            slot, S, shards = D.slot_map(ptr, oute, E, world, shards=D.shard_nodes_by_time(ptr, world, work_s, tail_s))
             nslots = world * S
         else:
             slot, S, nslots = np.arange(E, dtype=np.int32), E, E
-            shards = D.shard_nodes(ptr, nshard, cost) if nshard > 1 else [(0, N)]
+            shards = D.shard_nodes_by_time(ptr, nshard, work_s, tail_s) if nshard > 1 else [(0, N)]
         if shardable and (world > 1 or nshard > 1):
             # fails here, before any allocation, if a rank cannot hold slab + snapshot + its largest node (dist.memory_plan)
             D.memory_plan(ptr, 2, Mb, T, shards, nstates=nstates, hbm_bytes=float(torch.cuda.get_device_properties(dev).total_memory))

@@ -26,26 +26,27 @@ def node_costs(nbr_ptr, q, max_bond, T, nstates=None):
     return np.array([by_deg[int(d)] for d in deg])
 
 
-# Measured rates behind `node_times` (profiles/r02_config2_shard.json, r02_config3_*.log, r02_bench.json; MI355X):
-#   RATE_WG       executed flop rate of the workgroup engine at configs[1]-sized batches
-#   RATE_GRID     executed flop rate of the batched gauge sweep when many problems share a launch (configs[2] levels)
-#   PANEL_LATENCY wall time of one 16-column panel of ONE problem that has the chip to itself (launch sequence of the
-#                 batched QR + the truncating step): the degree-12 node of the configs[2] shard takes 92 s for 34
-#                 dependent products of T = 100 steps with 900 columns -> 92 / (34 * 100 * 57) s
+# Measured rates behind `node_times` (MI355X; profiles/r03_config2_all_shards.txt: every one of the 8 node blocks of configs[2]
+# run on one GPU, one saturated sweep each; r03_bench.json):
+#   RATE_WG        executed flop rate of the workgroup engine at configs[1]-sized batches
+#   RATE_GRID      executed flop rate of the batched gauge sweep when many problems share a launch (configs[2] levels)
+#   LEVEL_LATENCY  seconds per time step of a dependency level that holds ONE hub's problem alone: the levels of a node's
+#                  3z-2 cavity products (CavityTools order) deeper than a typical node's are not filled by other nodes, and a
+#                  single problem advances at the latency of its launch sequence, not at the flop rate.  Levels of different
+#                  hubs of one rank run in the SAME launches, so the rank pays for its deepest node only (max, not sum).
+# RATE_GRID and LEVEL_LATENCY are the least-squares fit of  time = flops / RATE_GRID + levels(z_max) T LEVEL_LATENCY  to the eight
+# measured blocks (245.8 ... 270.3 s, z_max 9 ... 12): residuals within 2 %.
 RATE_WG = 20e12
-RATE_GRID = 12e12
-PANEL_LATENCY = 92.0 / (34 * 100 * 57)
+RATE_GRID = 18e12
+LEVEL_LATENCY = 30e-3
 
 
 def node_times(nbr_ptr, q, max_bond, T, nstates=None, grid=None):
     """Predicted seconds of one node update: (work, tail).
-    `work` = executed flops / measured rate: it shares its launches with the other nodes of the rank.
-    `tail` = the part of the node's dependency chain that NOTHING shares: a node's 3z-2 cavity products (CavityTools order,
-    reference src/recursive_bp_factor.jl:140) run level by level; the levels up to the depth of a typical node (median
-    degree) are filled with many problems, the deeper ones hold this node's problem alone, and a single problem on the chip
-    advances at the latency of its launch sequence (PANEL_LATENCY per 16-column panel and time step), not at the flop rate.
-    Measured on the configs[2] shard: 299 s = the throughput part + the 92 s chain of its one degree-12 node.
-    The two ADD (launches on one stream are serial), so a rank's predicted time is sum(work + tail).
+    `work` = executed flops / measured rate: it shares its launches with the other nodes of the rank, a rank's work is the SUM.
+    `tail` = what the node adds if it is the DEEPEST of its rank: its dependency levels beyond those of a typical node
+    (median degree) hold its problem alone (see LEVEL_LATENCY); a rank's tail is the MAX over its nodes.
+    Predicted time of a rank = sum(work) + max(tail)  (`rank_times`, `shard_nodes_by_time`).
     `grid`: whether the batched gauge sweep is taken (default: the library's rule, Y_t rows > 2048)."""
     nbr_ptr = np.asarray(nbr_ptr, dtype=np.int64)
     deg = np.diff(nbr_ptr)
@@ -64,8 +65,52 @@ def node_times(nbr_ptr, q, max_bond, T, nstates=None, grid=None):
         g = (rows > 2048) if grid is None else grid
         work[i] = flops[i] / (RATE_GRID if g else RATE_WG)
         if g:
-            tail[i] = max(3 * z - 2 - d0, 0) * T * ((cols + 15) // 16) * PANEL_LATENCY
+            tail[i] = max(3 * z - 2 - d0, 0) * T * LEVEL_LATENCY
     return work, tail
+
+
+def rank_times(shards, work, tail):
+    """Predicted seconds per rank: sum of the work of its nodes + the tail of its deepest node."""
+    return np.array([float(np.sum(work[lo:hi])) + (float(np.max(tail[lo:hi])) if hi > lo else 0.0) for lo, hi in shards])
+
+
+def shard_nodes_by_time(nbr_ptr, world, work, tail):
+    """Contiguous node blocks that minimise the largest predicted rank time sum(work) + max(tail): bisection on the bound,
+    greedy packing from the left for a given bound (optimal for contiguous blocks: both terms grow with the block)."""
+    work = np.asarray(work, dtype=np.float64)
+    tail = np.asarray(tail, dtype=np.float64)
+    N = work.size
+
+    def pack(bound):
+        blocks, lo, w, t = [], 0, 0.0, 0.0
+        for i in range(N):
+            w2, t2 = w + work[i], max(t, tail[i])
+            if i > lo and w2 + t2 > bound:
+                blocks.append((lo, i))
+                lo, w2, t2 = i, work[i], tail[i]
+            w, t = w2, t2
+        blocks.append((lo, N))
+        return blocks
+
+    lo_b = float(np.max(work + tail)) if N else 0.0
+    hi_b = float(np.sum(work) + (np.max(tail) if N else 0.0))
+    for _ in range(60):
+        mid = 0.5 * (lo_b + hi_b)
+        if len(pack(mid)) <= world:
+            hi_b = mid
+        else:
+            lo_b = mid
+    blocks = pack(hi_b)
+    while len(blocks) < world:                 # fewer blocks than ranks (tiny graphs): split the largest
+        k = int(np.argmax([hi - lo for lo, hi in blocks]))
+        lo, hi = blocks[k]
+        if hi - lo < 2:
+            blocks.append((hi, hi))
+            continue
+        mid = (lo + hi) // 2
+        blocks[k:k + 1] = [(lo, mid), (mid, hi)]
+    blocks.sort()
+    return blocks
 
 
 def memory_plan(nbr_ptr, q, max_bond, T, shards, nstates=None, hbm_bytes=288e9, frac=0.85):
