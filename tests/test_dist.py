@@ -108,7 +108,8 @@ def test_cost_model_balances_config3_er_graph():
 
 # profiles/r03_config2_all_shards.txt
 MEASURED_CONFIG2_BLOCKS = {(0, 243): 270.3, (243, 527): 255.4, (527, 783): 245.8, (783, 1058): 258.8, (1054, 1313): 266.3,
-                           (1313, 1550): 246.9, (1550, 1802): 250.8}
+                           (1313, 1550): 246.9, (1550, 1802): 250.8, (1802, 2048): 272.2,
+                           (0, 226): 256.6, (1818, 2048): 258.4}          # the last two: hub ranks of the shipped cut, measured after the fit
 
 
 def test_time_model_balances_config2_for_8_ranks_and_memory_plan_fits():
