@@ -371,6 +371,10 @@ constexpr int L2_ROW = L2_PART + 512;       // [2][16]
 constexpr int L2_TAU = L2_ROW + 32;         // [64]
 constexpr int L2_FAC_TOTAL = L2_TAU + 64;   // 19552 doubles = 156,416 bytes
 constexpr int L2_SCR = IMG_V + 4 * 256;     // [4][256]: the cross-Gram slots of the operand images are free until the end
+// 512 bytes behind the image that nobody reads: the landing zone of the tile touches (touch_tile)
+constexpr int TOUCH_DOUBLES = 64;
+constexpr int UPD_LDS_DOUBLES = IMG_DOUBLES + TOUCH_DOUBLES;          // dynamic LDS of k_cq_upd
+constexpr int FAC_LDS_DOUBLES = L2_FAC_TOTAL + TOUCH_DOUBLES;         // dynamic LDS of k_cq_fac2 / k_cq_updfac
 
 template <int CJ>
 __device__ __forceinline__ double bcast16(double v) {
@@ -703,7 +707,8 @@ __device__ __forceinline__ void build_cross(int u, int nrb, int np, const ldbl* 
 }
 
 template <bool TREE>
-__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS);
+__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS,
+                                            int col_next, unsigned touch_off);
 
 // k_cq_fac2: grid (nodes of the level, problems), 256 threads, L2_FAC_TOTAL doubles of dynamic LDS.
 // la != 0: the node also updates its rows of the NEXT block's 64 columns (tiles 0..3, one per wave), so that the next
@@ -790,7 +795,7 @@ __device__ __forceinline__ void fac2_body(const v2::QrProb& Pr, int64_t ws_off, 
   }
   if (la) {
     const int col0 = jb + 64 + 16 * w;
-    if (col0 < cols16) update_tile<TREE>(Y, ld, base, nrb, col0, V, OPS);
+    if (col0 < cols16) update_tile<TREE>(Y, ld, base, nrb, col0, V, OPS, -1, 0u);
   }
 }
 
@@ -832,17 +837,41 @@ __device__ __forceinline__ void load_tile(const gdbl* Y, long ld, const int (&ba
     if (rb < nrb) C[rb] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
   }
 }
+// Touches the tile at column col_next: one 4-byte load per 128-byte line of the wave's 16 column segments (row group
+// (lane >> 4) + 4 k, column lane & 15), so that the real load one tile later hits the L2 instead of waiting for HBM.  A wave
+// of the update has no second wave on its SIMD to switch to, and a second tile buffer in registers spills (k_cq_upd).  The
+// loads go straight to an LDS landing zone nobody reads (global_load_lds_dword: no destination register, so nothing the
+// register allocator does can be hit by the late write) and are issued AFTER the wave has waited for its own tile, from
+// inline assembly the compiler's wait-count model does not see: no instruction waits for them, a later wait at most over-waits.
+__device__ __forceinline__ void touch_tile(const gdbl* Y, long ld, const int (&base)[4], int nrb, int col_next, unsigned lds_off) {
+#ifndef CQ_NO_TOUCH
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const gdbl* cp = Y + (long)(col_next + c) * ld;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int rb = g + 4 * k;
+    const int rbc = rb < nrb ? rb : 0;
+    const gdbl* p = cp + base[rbc >> 2] + 16 * (rbc & 3);
+    unsigned m0save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0save) : "v"(p), "s"(lds_off) : "memory");
+  }
+#endif
+}
 template <bool TREE>
-__device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS);
+__device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS,
+                                             int col_next, unsigned touch_off);
 template <bool TREE>
-__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS) {
+__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS,
+                                            int col_next, unsigned touch_off) {
   d4 C[16];
   load_tile(Y, ld, base, nrb, col0, C);
-  compute_tile<TREE>(Y, ld, base, nrb, col0, C, V, OPS);
+  compute_tile<TREE>(Y, ld, base, nrb, col0, C, V, OPS, col_next, touch_off);
 }
 // the tile in C (load_tile) against the node's image; the updated tile is stored
 template <bool TREE>
-__device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS) {
+__device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS,
+                                             int col_next, unsigned touch_off) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   gdbl* cp = Y + (long)(col0 + c) * ld + 4 * g;
   // LDS offsets: p even / odd variants absorb the bit-4 part of the swizzle
@@ -893,6 +922,10 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
       __builtin_amdgcn_sched_barrier(0);
     }
     w[p] = acc;
+    if (p == 0 && col_next >= 0) {              // the tile is in registers by now (the first MFMAs waited for it)
+      touch_tile(Y, ld, base, nrb, col_next, touch_off);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // ------------------------------------------------ phase B: W_p = T_p^T (W0_p - sum_{r<p} S_pr W_r)
 #pragma unroll
@@ -941,7 +974,7 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int level, int slot, int node, int tg, int tpg,
-                                         int tfirst, ldbl* lds) {
+                                         int tfirst, ldbl* lds, unsigned touch_off) {
   const int cols16 = (Pr.cols + 15) & ~15;
   if (jb + 64 > Pr.kmax || cols16 <= jb + 64) return;
   const int ntl = (cols16 - jb - 64) >> 4;
@@ -963,16 +996,18 @@ __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, i
   const int t1 = min(t0 + tpg, ntl);
   gdbl* Y = (gdbl*)Pr.Y;
   if (level == 0) {
-    for (int t = t0 + wave; t < t1; t += nwave) update_tile<false>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V);
+    for (int t = t0 + wave; t < t1; t += nwave)
+      update_tile<false>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V, (t + nwave < t1) ? jb + 64 + 16 * (t + nwave) : -1, touch_off);
   } else {
-    for (int t = t0 + wave; t < t1; t += nwave) update_tile<true>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V);
+    for (int t = t0 + wave; t < t1; t += nwave)
+      update_tile<true>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V, (t + nwave < t1) ? jb + 64 + 16 * (t + nwave) : -1, touch_off);
   }
 }
 
 template <int NT>
 __global__ void __launch_bounds__(NT) k_cq_upd(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int tpg, int tfirst) {
   extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
-  upd_body<NT>(probs[blockIdx.z], ws_off, jb, level, slot0 + blockIdx.y, blockIdx.y, blockIdx.x, tpg, tfirst, (ldbl*)cq_lds_raw);
+  upd_body<NT>(probs[blockIdx.z], ws_off, jb, level, slot0 + blockIdx.y, blockIdx.y, blockIdx.x, tpg, tfirst, (ldbl*)cq_lds_raw, (unsigned)(IMG_DOUBLES * 8));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1001,7 +1036,7 @@ __global__ void __launch_bounds__(256) k_cq_updfac(const v2::QrProb* probs, int 
   }
   b -= nprob * nfac;
   const int tg = b % ntg, node = (b / ntg) % nupd;
-  upd_body<256>(probs[b / (ntg * nupd)], ws_off, jb, level, slot_u + node, node, tg, tpg, 0, lds);
+  upd_body<256>(probs[b / (ntg * nupd)], ws_off, jb, level, slot_u + node, node, tg, tpg, 0, lds, (unsigned)(L2_FAC_TOTAL * 8));
 }
 
 }  // namespace cq
