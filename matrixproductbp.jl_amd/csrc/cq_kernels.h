@@ -366,15 +366,22 @@ __global__ void __launch_bounds__(256) k_cq_fac(const v2::QrProb* probs, int64_t
 // TREE: the node is a stack of four upper-triangular R factors, reflector j only touches rows <= j of segments 1..3
 // (the zero rows are skipped - 5/8 of the work on average).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int L2_PART = IMG_DOUBLES;        // [2][4][64]
+// LDS of the second form (68 KB: two node workgroups per CU).  The reflector image itself goes straight to the node's slot in
+// HBM; the LDS keeps the operand images, the exchange areas of the column steps and ONE 16-column panel of the image
+// (leading dimension 17: both MFMA operand shapes read it conflict free) for the in-register update of the later sub-panels.
+constexpr int F_OPS = 0;                    // [10][256] operand images
+constexpr int F_SCR = F_OPS + IMG_OPS;      // [4][256]
+constexpr int L2_PART = F_SCR + 4 * 256;    // [2][4][64]
 constexpr int L2_ROW = L2_PART + 512;       // [2][16]
 constexpr int L2_TAU = L2_ROW + 32;         // [64]
-constexpr int L2_FAC_TOTAL = L2_TAU + 64;   // 19552 doubles = 156,416 bytes
-constexpr int L2_SCR = IMG_V + 4 * 256;     // [4][256]: the cross-Gram slots of the operand images are free until the end
+constexpr int F_VP = L2_TAU + 64;           // [256][17] panel; after the last sub-panel: [3][4][256] cross-Gram partial sums
+constexpr int VP_LD = 17;
+constexpr int L2_FAC_TOTAL = F_VP + 256 * VP_LD;   // 8544 doubles = 68,352 bytes
 // 512 bytes behind the image that nobody reads: the landing zone of the tile touches (touch_tile)
 constexpr int TOUCH_DOUBLES = 64;
-constexpr int UPD_LDS_DOUBLES = IMG_DOUBLES + TOUCH_DOUBLES;          // dynamic LDS of k_cq_upd
-constexpr int FAC_LDS_DOUBLES = L2_FAC_TOTAL + TOUCH_DOUBLES;         // dynamic LDS of k_cq_fac2 / k_cq_updfac
+constexpr int UPD_LDS_DOUBLES = IMG_DOUBLES + TOUCH_DOUBLES;          // dynamic LDS of k_cq_upd and k_cq_updfac
+constexpr int FAC_LDS_DOUBLES = L2_FAC_TOTAL;                         // dynamic LDS of k_cq_fac2
+static_assert(L2_FAC_TOTAL <= IMG_DOUBLES, "the factor workgroups of k_cq_updfac live inside the update's LDS");
 
 template <int CJ>
 __device__ __forceinline__ double bcast16(double v) {
@@ -569,15 +576,16 @@ __device__ __forceinline__ void t_cols(const double (&grow)[16], double (&trow)[
   }
 }
 
-// After the column steps of sub-panel PJ: its reflectors into the LDS image, T_PJ (operand image in OPS slot PJ), and the
-// block-reflector update of the later sub-panels of the block in registers.
+// After the column steps of sub-panel PJ: its reflectors into the node's image (Vg: the slot in HBM, nullptr when nobody
+// will read it) and into the LDS panel, T_PJ (operand image in OPS slot PJ), and the block-reflector update of the later
+// sub-panels of the block in registers.
 template <int PJ, bool TREE>
-__device__ __forceinline__ void subpanel_finish(double (&P)[4][4][4], const double (&mytau)[4], int w, int mycnt, int np, ldbl* lds) {
+__device__ __forceinline__ void subpanel_finish(double (&P)[4][4][4], const double (&mytau)[4], int w, int mycnt, int np, ldbl* lds, gdbl* Vg) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  ldbl* V = lds;
-  ldbl* OPS = lds + IMG_V;
+  ldbl* Vp = lds + F_VP;
+  ldbl* OPS = lds + F_OPS;
   ldbl* tauL = lds + L2_TAU;
-  ldbl* scr = lds + L2_SCR;
+  ldbl* scr = lds + F_SCR;
   {
     d4 acc = d4{0, 0, 0, 0};
 #pragma unroll
@@ -588,7 +596,8 @@ __device__ __forceinline__ void subpanel_finish(double (&P)[4][4][4], const doub
         double v = P[rb][e][PJ];
         if (w == 0) v = (rl > col) ? v : ((rl == col) ? 1.0 : 0.0);
         if (16 * rb >= mycnt) v = 0.0;
-        V[(64 * w + rl) * 64 + (col ^ swz(4 * g + e))] = v;
+        if (Vg) Vg[(64 * w + rl) * 64 + (col ^ swz(4 * g + e))] = v;
+        Vp[(64 * w + rl) * VP_LD + c] = v;
         if (!(TREE && rb > PJ)) acc = mfma(v, v, acc);
       }
 #pragma unroll
@@ -630,8 +639,8 @@ __device__ __forceinline__ void subpanel_finish(double (&P)[4][4][4], const doub
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int m = 4 * g + e;
-        aA[rb][e] = V[(64 * w + 16 * rb + m) * 64 + ((16 * PJ + sc) ^ swz(m))];
-        aC[rb][e] = V[(64 * w + 16 * rb + sc) * 64 + ((16 * PJ + m) ^ swz(sc))];
+        aA[rb][e] = Vp[(64 * w + 16 * rb + m) * VP_LD + sc];          // own rows only: no other wave writes or reads them
+        aC[rb][e] = Vp[(64 * w + 16 * rb + sc) * VP_LD + m];
       }
     }
     double timg[4];
@@ -677,32 +686,60 @@ __device__ __forceinline__ void subpanel_finish(double (&P)[4][4][4], const doub
   }
 }
 
-// cross Grams of the finished image -> S_pr operand images (slots 4..9), shared out to the four waves
-__device__ __forceinline__ void build_cross(int u, int nrb, int np, const ldbl* V, ldbl* OPS) {
+// Cross Grams S_pr = V_p^T V_r (r < p) of the finished node -> operand images in OPS slots 4..9, from the registers: the
+// sub-panels still sit in P (below the pivots; wave 0's triangle is masked to the unit-lower-trapezoidal head on the fly).
+// Two rounds of three blocks; the partial sums of the four waves meet in the panel area, which is free by now.
+//   blocks: 4 + p(p-1)/2 + r = (p,r).  G_pr[i][j] = sum_rows V[row][16p+i] V[row][16r+j]
+template <bool TREE>
+__device__ __forceinline__ void cross_grams(const double (&P)[4][4][4], int w, int mycnt, int np, ldbl* lds) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  for (int b = 4 + u; b < 10; b += 4) {
-    const int q = b - 4;
-    const int p = (q < 1) ? 1 : ((q < 3) ? 2 : 3), r = q - p * (p - 1) / 2;
-    ldbl* G = OPS + b * 256;
-    d4 acc = d4{0, 0, 0, 0};
-    if (p < np) {
-      for (int rb = 0; rb < nrb; rb++) {
+  ldbl* OPS = lds + F_OPS;
+  ldbl* part = lds + F_VP;                      // [3][4][256]
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int b = 4 + 3 * round + k;
+      const int q = b - 4;
+      const int p = (q < 1) ? 1 : ((q < 3) ? 2 : 3), r = q - p * (p - 1) / 2;
+      d4 acc = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int rb = 0; rb < 4; rb++) {
+        if (TREE && rb > r) continue;             // sub-panel r of a stack of triangles is zero below row group r
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const int m = 4 * g + e, z = swz(m);
-          const double a = V[(16 * rb + m) * 64 + ((16 * p + c) ^ z)];
-          const double bb = V[(16 * rb + m) * 64 + ((16 * r + c) ^ z)];
+          const int rl = 16 * rb + 4 * g + e;
+          double a = P[rb][e][p], bb = P[rb][e][r];
+          if (w == 0) {
+            a = (rl > 16 * p + c) ? a : ((rl == 16 * p + c) ? 1.0 : 0.0);
+            bb = (rl > 16 * r + c) ? bb : ((rl == 16 * r + c) ? 1.0 : 0.0);
+          }
+          if (16 * rb >= mycnt || p >= np) { a = 0.0; bb = 0.0; }
           acc = mfma(a, bb, acc);
         }
       }
+#pragma unroll
+      for (int e = 0; e < 4; e++) part[(k * 4 + w) * 256 + 64 * e + lane] = acc[e];
     }
+    lds_barrier();
+    if (w < 3) {
+      const int b = 4 + 3 * round + w;
+      ldbl* G = OPS + b * 256;
+      // plain block G[i = g + 4e][j = c], then the image Simg[s][lane] = -S_pr[sig(c)][4g + s] in place (same wave, in order)
 #pragma unroll
-    for (int e = 0; e < 4; e++) G[(g + 4 * e) + 16 * c] = acc[e];
-    double img[4];
+      for (int e = 0; e < 4; e++) {
+        double sgm = 0.0;
 #pragma unroll
-    for (int s = 0; s < 4; s++) img[s] = -G[sig(c) + 16 * (4 * g + s)];
+        for (int ww = 0; ww < 4; ww++) sgm += part[(w * 4 + ww) * 256 + 64 * e + lane];
+        G[(g + 4 * e) + 16 * c] = sgm;
+      }
+      double img[4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) G[64 * s + lane] = img[s];
+      for (int s2 = 0; s2 < 4; s2++) img[s2] = -G[sig(c) + 16 * (4 * g + s2)];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) G[64 * s2 + lane] = img[s2];
+    }
+    lds_barrier();
   }
 }
 
@@ -710,12 +747,11 @@ template <bool TREE>
 __device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS,
                                             int col_next, unsigned touch_off);
 
-// k_cq_fac2: grid (nodes of the level, problems), 256 threads, L2_FAC_TOTAL doubles of dynamic LDS.
-// la != 0: the node also updates its rows of the NEXT block's 64 columns (tiles 0..3, one per wave), so that the next
-// block's factorisations depend on this launch chain only and the other tiles can follow on a second stream.
+// k_cq_fac2: grid (nodes of the level, problems), 256 threads, FAC_LDS_DOUBLES doubles of dynamic LDS (two workgroups per CU).
 template <bool TREE>
 __device__ __forceinline__ void fac2_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int slot, const int (&base)[4], const int (&cnt)[4],
                                           int la, ldbl* lds) {
+  (void)la;
   const int np = min(4, (Pr.kmax - jb + 15) >> 4);
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -723,10 +759,12 @@ __device__ __forceinline__ void fac2_body(const v2::QrProb& Pr, int64_t ws_off, 
   const long ld = Pr.ld;
   const int mybase = (w == 0) ? base[0] : (w == 1) ? base[1] : (w == 2) ? base[2] : base[3];
   const int mycnt = (w == 0) ? cnt[0] : (w == 1) ? cnt[1] : (w == 2) ? cnt[2] : cnt[3];
-  ldbl* V = lds;
-  ldbl* OPS = lds + IMG_V;
+  ldbl* OPS = lds + F_OPS;
   const int cols16 = (Pr.cols + 15) & ~15;
   const bool trailing = cols16 > jb + 64;
+  // the node's image: [256][64] reflectors (XOR-swizzled) + the operand images, read by the update of this level
+  gdbl* slotp = (gdbl*)Pr.aux + ws_off + (long)slot * IMG_DOUBLES;
+  gdbl* Vg = trailing ? slotp : nullptr;
 
   double P[4][4][4];
   double mytau[4] = {0.0, 0.0, 0.0, 0.0};
@@ -742,16 +780,11 @@ __device__ __forceinline__ void fac2_body(const v2::QrProb& Pr, int64_t ws_off, 
         for (int e = 0; e < 4; e++) P[rb][e][p] = v[e];
       }
   }
-#if defined(CQ_VAR) && CQ_VAR == 5
-  subpanel_steps<0, TREE>(P, mytau, w, lds); subpanel_steps<1, TREE>(P, mytau, w, lds);
-  subpanel_steps<2, TREE>(P, mytau, w, lds); subpanel_steps<3, TREE>(P, mytau, w, lds);
-#else
   subpanel_steps<0, TREE>(P, mytau, w, lds);
-  subpanel_finish<0, TREE>(P, mytau, w, mycnt, np, lds);
-  if (np > 1) { subpanel_steps<1, TREE>(P, mytau, w, lds); subpanel_finish<1, TREE>(P, mytau, w, mycnt, np, lds); }
-  if (np > 2) { subpanel_steps<2, TREE>(P, mytau, w, lds); subpanel_finish<2, TREE>(P, mytau, w, mycnt, np, lds); }
-  if (np > 3) { subpanel_steps<3, TREE>(P, mytau, w, lds); subpanel_finish<3, TREE>(P, mytau, w, mycnt, np, lds); }
-#endif
+  subpanel_finish<0, TREE>(P, mytau, w, mycnt, np, lds, Vg);
+  if (np > 1) { subpanel_steps<1, TREE>(P, mytau, w, lds); subpanel_finish<1, TREE>(P, mytau, w, mycnt, np, lds, Vg); }
+  if (np > 2) { subpanel_steps<2, TREE>(P, mytau, w, lds); subpanel_finish<2, TREE>(P, mytau, w, mycnt, np, lds, Vg); }
+  if (np > 3) { subpanel_steps<3, TREE>(P, mytau, w, lds); subpanel_finish<3, TREE>(P, mytau, w, mycnt, np, lds, Vg); }
   // R to its place (first segment: upper triangle, zeros below)
   if (w == 0) {
     gdbl* dst = Y + (long)(jb + c) * ld + mybase + 4 * g;
@@ -778,30 +811,22 @@ __device__ __forceinline__ void fac2_body(const v2::QrProb& Pr, int64_t ws_off, 
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-          for (int e = 0; e < 4; e++) V[(64 * w + 16 * rb + 4 * g + e) * 64 + ((16 * p + c) ^ swz(4 * g + e))] = 0.0;
+          for (int e = 0; e < 4; e++) Vg[(64 * w + 16 * rb + 4 * g + e) * 64 + ((16 * p + c) ^ swz(4 * g + e))] = 0.0;
         for (int i = lane; i < 256; i += 64) if (w == 0) OPS[p * 256 + i] = 0.0;
       }
     lds_barrier();
   }
-  const int nrb = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) >> 4;
-  build_cross(w, nrb, np, V, OPS);
-  lds_barrier();
-  // image -> the node's slot
+  cross_grams<TREE>(P, w, mycnt, np, lds);
+  // the operand images -> behind the reflectors in the node's slot
   {
-    gd4* dstv = reinterpret_cast<gd4*>((gdbl*)Pr.aux + ws_off + (long)slot * IMG_DOUBLES);
+    gd4* dstv = reinterpret_cast<gd4*>(slotp + IMG_V);
     typedef __attribute__((address_space(3))) d4 ld4;
-    const ld4* srcv = reinterpret_cast<const ld4*>(lds);
-    for (int i = tid; i < IMG_DOUBLES / 4; i += 256) __builtin_nontemporal_store(srcv[i], dstv + i);
-  }
-  if (la) {
-    const int col0 = jb + 64 + 16 * w;
-    if (col0 < cols16) update_tile<TREE>(Y, ld, base, nrb, col0, V, OPS, -1, 0u);
+    const ld4* srcv = reinterpret_cast<const ld4*>(OPS);
+    for (int i = tid; i < IMG_OPS / 4; i += 256) dstv[i] = srcv[i];
   }
 }
 
-__global__ void __launch_bounds__(256) k_cq_fac2(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int la) {
-  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
-  ldbl* lds = (ldbl*)cq_lds_raw;
+__device__ __forceinline__ void fac2_kernel_body(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int la, ldbl* lds) {
   const v2::QrProb Pr = probs[blockIdx.y];
   if (jb >= Pr.kmax) return;
   const int rows32 = (Pr.rows + 31) & ~31;
@@ -817,6 +842,17 @@ __global__ void __launch_bounds__(256) k_cq_fac2(const v2::QrProb* probs, int64_
 #endif
   if (level == 0) fac2_body<false>(Pr, ws_off, jb, slot0 + blockIdx.x, base, cnt, la, lds);
   else fac2_body<true>(Pr, ws_off, jb, slot0 + blockIdx.x, base, cnt, la, lds);
+}
+// Two builds of the same body: k_cq_fac2 with the whole register file of a SIMD for its wave (256 + ~170 registers, no scratch:
+// the fastest single node, 81 us - taken when the launch has at most one node per CU), k_cq_fac2x2 at two waves per SIMD
+// (256 registers, the spills sit outside the column steps; a node takes 90 us but two share a CU: the many-node launches).
+__global__ void __launch_bounds__(256) k_cq_fac2(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int la) {
+  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
+  fac2_kernel_body(probs, ws_off, jb, level, slot0, la, (ldbl*)cq_lds_raw);
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_cq_fac2x2(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int la) {
+  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
+  fac2_kernel_body(probs, ws_off, jb, level, slot0, la, (ldbl*)cq_lds_raw);
 }
 
 // One trailing tile (256 node rows in four segments x 16 columns at col0) against the node's LDS image.
@@ -1036,7 +1072,7 @@ __global__ void __launch_bounds__(256) k_cq_updfac(const v2::QrProb* probs, int 
   }
   b -= nprob * nfac;
   const int tg = b % ntg, node = (b / ntg) % nupd;
-  upd_body<256>(probs[b / (ntg * nupd)], ws_off, jb, level, slot_u + node, node, tg, tpg, 0, lds, (unsigned)(L2_FAC_TOTAL * 8));
+  upd_body<256>(probs[b / (ntg * nupd)], ws_off, jb, level, slot_u + node, node, tg, tpg, 0, lds, (unsigned)(IMG_DOUBLES * 8));
 }
 
 }  // namespace cq

@@ -167,6 +167,7 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       hipFuncSetAttribute((const void*)cq::k_cq_upd<512>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
       hipFuncSetAttribute((const void*)cq::k_cq_upd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
       hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
+      hipFuncSetAttribute((const void*)cq::k_cq_fac2x2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
       int ncu = 256;
       { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; }
       // One stream, one launch after the other.  Measured and dropped (round 3): (a) the upper-level factorisations of a
@@ -176,7 +177,7 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       // ones: 6400 x 1600 x 16 26.9 -> 28.0 / 34.5 ms, 7200 x 900 x 128 69.9 -> 67.1 / 71.6 ms.
       // Per block: F_0, then one launch per level with the update U_l and the next level's factorisation F_{l+1} (k_cq_updfac).
       static const bool no_fuse = getenv("MPBP_DEBUG_CQ_NOFUSE") != nullptr;
-      hipFuncSetAttribute((const void*)cq::k_cq_updfac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
+      hipFuncSetAttribute((const void*)cq::k_cq_updfac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
       const int cols16_max = r16i(cols_max);
       // tiles per workgroup: one tile per wave and four-wave workgroups for the small upper levels; else the number of tile
       // groups with the fewest (rounds over the CUs) x (time of a workgroup: ~12 us of image load + 6.2 us per tile, measured
@@ -199,7 +200,9 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
         int nl[12], nlev = 0;
         for (int n = (rows32_max - jb + 255) / 256; nlev < 12; n = (n + 3) / 4) { nl[nlev++] = n; if (n == 1) break; }
         int slot = 0;
-        hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[0], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, 0, 0, 0);
+        // more nodes than CUs: the two-per-CU build of the factor kernel
+        if ((int64_t)nl[0] * P > ncu) hipLaunchKernelGGL(cq::k_cq_fac2x2, dim3(nl[0], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, 0, 0, 0);
+        else hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[0], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, 0, 0, 0);
         for (int level = 0; level < nlev; level++) {
           const int n = nl[level];
           const bool more = level + 1 < nlev;
@@ -208,14 +211,17 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
           const int ntg = ntl > 0 ? (ntl + tpg - 1) / tpg : 0;
           if (ntl > 0 && more && !no_fuse) {
             const int64_t wgs = (int64_t)P * nl[level + 1] + (int64_t)P * n * ntg;
-            hipLaunchKernelGGL(cq::k_cq_updfac, dim3((unsigned)wgs), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, P, ws_off, jb, level, slot, n, ntg,
+            hipLaunchKernelGGL(cq::k_cq_updfac, dim3((unsigned)wgs), dim3(256), cq::UPD_LDS_DOUBLES * 8, st, d_probs, P, ws_off, jb, level, slot, n, ntg,
                                tpg, slot + n, nl[level + 1]);
           } else {
             if (ntl > 0) {
               if (nthr == 256) hipLaunchKernelGGL(cq::k_cq_upd<256>, dim3(ntg, n, P), dim3(256), cq::UPD_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level, slot, tpg, 0);
               else hipLaunchKernelGGL(cq::k_cq_upd<512>, dim3(ntg, n, P), dim3(512), cq::UPD_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level, slot, tpg, 0);
             }
-            if (more) hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[level + 1], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level + 1, slot + n, 0);
+            if (more) {
+              if ((int64_t)nl[level + 1] * P > ncu) hipLaunchKernelGGL(cq::k_cq_fac2x2, dim3(nl[level + 1], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level + 1, slot + n, 0);
+              else hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[level + 1], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level + 1, slot + n, 0);
+            }
           }
           slot += n;
         }

@@ -17,7 +17,7 @@ int main() {
   hipMemcpy(dY, Y.data(), Y.size() * 8, hipMemcpyHostToDevice);
   v2::QrProb hp{dY, dAux, ld, rows, cols, cols};
   hipMemcpy(dP, &hp, sizeof hp, hipMemcpyHostToDevice);
-  hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::L2_FAC_TOTAL * 8);
+  hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int level = 0; level < 2; level++)
     for (int n : {1, 16, 64}) {
@@ -25,7 +25,7 @@ int main() {
       for (int rep = 0; rep < 3; rep++) {
         hipMemcpy(dY, Y.data(), Y.size() * 8, hipMemcpyHostToDevice);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(cq::k_cq_fac2, dim3(n, 1), dim3(256), cq::L2_FAC_TOTAL * 8, 0, dP, (int64_t)4096, 0, level, 0, 0);
+        hipLaunchKernelGGL(cq::k_cq_fac2, dim3(n, 1), dim3(256), cq::FAC_LDS_DOUBLES * 8, 0, dP, (int64_t)4096, 0, level, 0, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep == 2) printf("variant %d level %d nodes %2d: %.1f us\n", CQ_VAR, level, n, ms * 1e3);
