@@ -136,6 +136,27 @@ def test_qr_batched_tall(rows, cols):
         assert np.abs(R[p] * sgn[:, None] - Rn).max() < 1e-11 * np.abs(Rn).max()
 
 
+def test_qr_batched_tree_many_nodes_two_per_cu_and_ragged_tail():
+    """The communication-avoiding form (csrc/cq_kernels.h) with more level-0 nodes than CUs: the two-per-CU build of the node
+    factorisation (k_cq_fac2x2), upper levels inside the fused update + factorisation launches, a last node of 32 rows
+    (rows = 2112 + 32) and rank-deficient / badly scaled columns; every problem against LAPACK."""
+    rng = np.random.default_rng(24)
+    for (r, c, nprob) in [(4128, 192, 40), (2144, 320, 36)]:
+        A = rng.standard_normal((nprob, r, c)) * np.logspace(0, -10, c)[None, None, :]
+        A[1, :, 5] = A[1, :, 4]                     # a dependent column
+        A[2, :, c // 2:] *= 1e-140                  # numerically null trailing half
+        R, _ = _qr_batched(A, 0)
+        assert np.isfinite(R).all()
+        for p in range(nprob):
+            G1, G2 = R[p].T @ R[p], A[p].T @ A[p]
+            assert np.abs(G1 - G2).max() <= 1e-12 * max(np.abs(G2).max(), 1e-300), (r, c, p)
+        for p in (0, 7, nprob - 1):
+            Rn = np.linalg.qr(A[p], mode="r")
+            sgn = np.sign(np.diag(Rn)) * np.sign(np.diag(R[p]))
+            sgn[sgn == 0] = 1
+            assert np.abs(R[p] * sgn[:, None] - Rn).max() < 1e-11 * np.abs(Rn).max(), (r, c, p)
+
+
 def test_qr_batched_many_problems_fused_update():
     """Enough problems for the wave-per-tile-pair fused trailing update (k_trail4f) and the one-launch register panels
     with Gram + T (k_fpanel), the path a configs[1]-sized batch takes in the batched gauge sweep."""
