@@ -12,10 +12,11 @@
 //             the stacked R factors; the root's R lands in rows [64 k, 64 k + 64) - where R_k belongs
 //
 // so the reflectors of a node touch only the node's 256 rows.  Two kernels per level:
-//   k_cq_fac  one 256-thread workgroup per node: the 64 column steps entirely in registers (rows across lanes in the MFMA
-//             B-operand layout, a column's dot products are in-lane sums + two butterfly levels + one LDS exchange of the
-//             four waves), then the node's reflectors as an XOR-swizzled LDS image + the T / cross-Gram operand images
-//             (MFMA Gram of the image, dlarft recurrence), copied to the node's slot of the per-problem scratch
+//   k_cq_fac2 one 256-thread workgroup per node: the 64 column steps entirely in registers (rows across lanes in the MFMA
+//             B-operand layout; a column is broadcast along its 16-lane row with DPP, its dot products are in-lane sums +
+//             two permlane levels + one LDS exchange of the four waves), the later sub-panels updated on the matrix pipes;
+//             the node's reflectors go to its slot of the per-problem scratch as an XOR-swizzled image, followed by the
+//             T / cross-Gram operand images (MFMA Grams from the registers, dlarft recurrence)
 //   k_cq_upd  workgroups over (tile group, node, problem): the image (148 KB) into LDS once, then every wave takes
 //             256 x 16 tiles of the trailing matrix: read ONCE into registers, W0 = V^T C, W = T-recurrence, C -= V W,
 //             written ONCE.  Measured alone (tools/probes/caqr_update_probe.hip): 60 % of the fp64 MFMA peak with 256
@@ -39,12 +40,6 @@ using namespace wgc;
 constexpr int IMG_V = 256 * 64;             // doubles
 constexpr int IMG_OPS = 10 * 256;
 constexpr int IMG_DOUBLES = IMG_V + IMG_OPS;          // one node's slot in the scratch: 18944 doubles = 151,552 bytes
-// LDS of k_cq_fac behind the image
-constexpr int L_PART = IMG_DOUBLES;         // [2][4][64]
-constexpr int L_ROW = L_PART + 512;         // [2][64]
-constexpr int L_TAU = L_ROW + 128;          // [64]
-constexpr int L_FAC_TOTAL = L_TAU + 64;     // 19648 doubles = 157,184 bytes
-
 __device__ __forceinline__ int swz(int m) { return (m & 3) | (m & 8) | ((m & 4) << 2); }
 __device__ __forceinline__ int sig(int i) { return 4 * (i & 3) + (i >> 2); }
 
@@ -71,16 +66,6 @@ __device__ __forceinline__ bool node_segments(int rows32, int j0, int level, int
   return level == 0 ? (cnt[0] > 0) : (nseg >= 2);
 }
 
-__device__ __forceinline__ double bperm(double x, int srclane) {
-  const int lo = __builtin_amdgcn_ds_bpermute(srclane << 2, __double2loint(x));
-  const int hi = __builtin_amdgcn_ds_bpermute(srclane << 2, __double2hiint(x));
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double xor_add(double v, int mask) {
-  const int lane = threadIdx.x & 63;
-  return v + bperm(v, lane ^ mask);
-}
-
 struct Refl { double beta, tau, scale; };
 // LAPACK dlarfg from the pivot and the squared norm below it (rsq / rcp + Newton, as v2::reflector)
 __device__ __forceinline__ Refl dlarfg(double alpha, double ss) {
@@ -102,262 +87,8 @@ __device__ __forceinline__ Refl dlarfg(double alpha, double ss) {
   return r;
 }
 
-// The sixteen column steps of sub-panel PJ of a node.  P[rb][e][p]: node row 64 w + 16 rb + 4 g + e, block column
-// 16 p + c; the pivot rows are the node's first 64 rows (wave 0).  One workgroup barrier per column (the partial sums
-// and the pivot row are double buffered).
-template <int PJ>
-__device__ __forceinline__ void panel16(double (&P)[4][4][4], double (&mytau)[4], int w, ldbl* lds, int& step) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  ldbl* part = lds + L_PART;
-  ldbl* rowb = lds + L_ROW;
-  for (int cj = 0; cj < 16; cj++) {
-    const int j = 16 * PJ + cj;
-    const int par = step & 1;
-    step++;
-    const int src = (lane & 48) | cj;
-    double x[4][4];
-#pragma unroll
-    for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        double v = bperm(P[rb][e][PJ], src);
-        const bool incl = (w > 0) || (rb > PJ) || (rb == PJ && 4 * g + e > cj);
-        x[rb][e] = incl ? v : 0.0;
-      }
-    // column sums of x .* P over this wave's rows
-    double d[4];
-#pragma unroll
-    for (int p = PJ; p < 4; p++) {
-      double s = 0.0;
-#pragma unroll
-      for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) s += x[rb][e] * P[rb][e][p];
-      s = xor_add(s, 16);
-      s = xor_add(s, 32);
-      d[p] = s;
-    }
-    if (g == 0) {
-#pragma unroll
-      for (int p = PJ; p < 4; p++) part[par * 256 + w * 64 + 16 * p + c] = d[p];
-    }
-    // the pivot row of this step, columns of the block from sub-panel PJ on
-    if (w == 0 && g == (cj >> 2)) {
-      const int ee = cj & 3;
-#pragma unroll
-      for (int p = PJ; p < 4; p++) {
-        const double v = (ee == 0) ? P[PJ][0][p] : (ee == 1) ? P[PJ][1][p] : (ee == 2) ? P[PJ][2][p] : P[PJ][3][p];
-        rowb[par * 64 + 16 * p + c] = v;
-      }
-    }
-    lds_barrier();
-    double ss = 0.0, dt[4], rv[4];
-#pragma unroll
-    for (int ww = 0; ww < 4; ww++) ss += part[par * 256 + ww * 64 + 16 * PJ + cj];
-#pragma unroll
-    for (int p = PJ; p < 4; p++) {
-      double s = 0.0;
-#pragma unroll
-      for (int ww = 0; ww < 4; ww++) s += part[par * 256 + ww * 64 + 16 * p + c];
-      dt[p] = s;
-      rv[p] = rowb[par * 64 + 16 * p + c];
-    }
-    const double alpha = rowb[par * 64 + j];
-    const Refl h = dlarfg(alpha, ss);
-    mytau[PJ] = (c == cj) ? h.tau : mytau[PJ];
-    double tw[4];
-#pragma unroll
-    for (int p = PJ; p < 4; p++) {
-      const double t = h.tau * (rv[p] + h.scale * dt[p]);
-      tw[p] = (p == PJ && c <= cj) ? 0.0 : t;
-    }
-    const bool iscj = (c == cj);
-#pragma unroll
-    for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const double v = x[rb][e] * h.scale;
-        const bool incl = (w > 0) || (rb > PJ) || (rb == PJ && 4 * g + e > cj);
-        const double upd = P[rb][e][PJ] - v * tw[PJ];
-        P[rb][e][PJ] = (iscj && incl) ? v : upd;
-#pragma unroll
-        for (int p = PJ + 1; p < 4; p++) P[rb][e][p] -= v * tw[p];
-      }
-    // the pivot row itself: v = 1 there
-    if (w == 0 && g == (cj >> 2)) {
-      const int ee = cj & 3;
-#pragma unroll
-      for (int p = PJ; p < 4; p++) {
-        const double nv = (p == PJ && iscj) ? h.beta : (rv[p] - tw[p]);
-#pragma unroll
-        for (int e = 0; e < 4; e++) P[PJ][e][p] = (e == ee) ? nv : P[PJ][e][p];
-      }
-    }
-  }
-}
-
-// T of a sixteen-reflector panel from its Gram matrix (dlarft): row i of T depends only on its own earlier entries.
-//   T(i,j) = -tau_j sum_{i2=i}^{j-1} T(i,i2) G(i2,j)  (i < j),  T(j,j) = tau_j.     G: plain 16 x 16, [i + 16 j]
-__device__ __forceinline__ void t_from_gram(const ldbl* G, const ldbl* tau, double (&trow)[16], int i) {
-#pragma unroll
-  for (int j = 0; j < 16; j++) {
-    double gcol[16];
-#pragma unroll
-    for (int i2 = 0; i2 < 16; i2++) gcol[i2] = G[i2 + 16 * j];
-    const double tj = tau[j];
-    double sacc = 0.0;
-#pragma unroll
-    for (int i2 = 0; i2 < j; i2++) sacc += (i2 >= i) ? trow[i2] * gcol[i2] : 0.0;
-    trow[j] = (j == i) ? tj : ((j > i) ? -tj * sacc : 0.0);
-  }
-}
-
-// Gram blocks of the LDS image -> T_p and S_pr operand images.  Called by the four waves (u = 0..3) together; two barriers.
-//   blocks: 0..3 = (p,p); 4 + p(p-1)/2 + r = (p,r).  G_pr[i][j] = sum_rows V[row][16p+i] V[row][16r+j]
-__device__ __forceinline__ void build_images(int u, int nrb, int np, const ldbl* V, ldbl* OPS, const ldbl* tauL) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  for (int b = u; b < 10; b += 4) {
-    int p, r;
-    if (b < 4) { p = b; r = b; }
-    else { const int q = b - 4; p = (q < 1) ? 1 : ((q < 3) ? 2 : 3); r = q - p * (p - 1) / 2; }
-    ldbl* G = OPS + b * 256;
-    d4 acc = d4{0, 0, 0, 0};
-    if (p < np) {
-      for (int rb = 0; rb < nrb; rb++) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int m = 4 * g + e, z = swz(m);
-          const double a = V[(16 * rb + m) * 64 + ((16 * p + c) ^ z)];
-          const double bb = V[(16 * rb + m) * 64 + ((16 * r + c) ^ z)];
-          acc = mfma(a, bb, acc);
-        }
-      }
-    }
-    // plain block: G[i = g + 4e][j = c]
-#pragma unroll
-    for (int e = 0; e < 4; e++) G[(g + 4 * e) + 16 * c] = acc[e];
-  }
-  lds_barrier();
-  // diagonal blocks -> T_p (wave u builds T_u), cross blocks -> image in place
-  for (int b = u; b < 10; b += 4) {
-    int p, r;
-    if (b < 4) { p = b; r = b; }
-    else { const int q = b - 4; p = (q < 1) ? 1 : ((q < 3) ? 2 : 3); r = q - p * (p - 1) / 2; }
-    (void)r;
-    ldbl* G = OPS + b * 256;
-    double img[4];
-    if (b < 4) {
-      double trow[16];
-      if (lane < 16) {
-        t_from_gram(G, tauL + 16 * p, trow, lane);
-#pragma unroll
-        for (int j = 0; j < 16; j++) G[lane + 16 * j] = trow[j];       // every lane has finished reading G (same wave, in order)
-      }
-      // Timg[s][lane (g, c)] = T[4g + s][sig(c)]
-#pragma unroll
-      for (int s = 0; s < 4; s++) img[s] = G[(4 * g + s) + 16 * sig(c)];
-    } else {
-      // Simg[s][lane] = -S_pr[sig(c)][4g + s]
-#pragma unroll
-      for (int s = 0; s < 4; s++) img[s] = -G[sig(c) + 16 * (4 * g + s)];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; s++) G[64 * s + lane] = img[s];
-  }
-  lds_barrier();
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// k_cq_fac: grid (nodes of the level, problems), 256 threads, L_FAC_TOTAL doubles of dynamic LDS.
-// ws_off: offset (doubles) of the node slots inside QrProb::aux; slot0: the level's first slot.
-// ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_cq_fac(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0) {
-  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
-  ldbl* lds = (ldbl*)cq_lds_raw;
-  const v2::QrProb Pr = probs[blockIdx.y];
-  if (jb >= Pr.kmax) return;
-  const int rows32 = (Pr.rows + 31) & ~31;
-  int base[4], cnt[4];
-  if (!node_segments(rows32, jb, level, blockIdx.x, base, cnt)) return;
-  const int np = min(4, (Pr.kmax - jb + 15) >> 4);
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, c = lane & 15;
-  gdbl* Y = (gdbl*)Pr.Y;
-  const long ld = Pr.ld;
-  const int mybase = (w == 0) ? base[0] : (w == 1) ? base[1] : (w == 2) ? base[2] : base[3];
-  const int mycnt = (w == 0) ? cnt[0] : (w == 1) ? cnt[1] : (w == 2) ? cnt[2] : cnt[3];
-  ldbl* V = lds;
-  ldbl* OPS = lds + IMG_V;
-  ldbl* tauL = lds + L_TAU;
-
-  double P[4][4][4];
-  double mytau[4] = {0.0, 0.0, 0.0, 0.0};
-  {
-    const gdbl* src = Y + (long)(jb + c) * ld + mybase + 4 * g;
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-      for (int rb = 0; rb < 4; rb++) {
-        d4 v = d4{0, 0, 0, 0};
-        if (p < np && 16 * rb < mycnt) v = *reinterpret_cast<const gd4*>(src + (long)(16 * p) * ld + 16 * rb);
-#pragma unroll
-        for (int e = 0; e < 4; e++) P[rb][e][p] = v[e];
-      }
-  }
-  int step = 0;
-  panel16<0>(P, mytau, w, lds, step);
-  if (np > 1) panel16<1>(P, mytau, w, lds, step);
-  if (np > 2) panel16<2>(P, mytau, w, lds, step);
-  if (np > 3) panel16<3>(P, mytau, w, lds, step);
-
-  // reflector image (unit lower trapezoidal head in the first 64 rows), taus, and R to its place
-#pragma unroll
-  for (int p = 0; p < 4; p++)
-#pragma unroll
-    for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int row = 64 * w + 16 * rb + 4 * g + e, col = 16 * p + c;
-        double v = P[rb][e][p];
-        if (w == 0) v = (row > col) ? v : ((row == col) ? 1.0 : 0.0);
-        if (16 * rb >= mycnt || p >= np) v = 0.0;
-        V[row * 64 + (col ^ swz(4 * g + e))] = v;
-      }
-  if (w == 0 && g == 0) {
-#pragma unroll
-    for (int p = 0; p < 4; p++) tauL[16 * p + c] = mytau[p];
-  }
-  if (w == 0) {
-    gdbl* dst = Y + (long)(jb + c) * ld + mybase + 4 * g;
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-      if (p < np) {
-#pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
-          if (16 * rb < mycnt) {
-            d4 v;
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = (16 * rb + 4 * g + e <= 16 * p + c) ? P[rb][e][p] : 0.0;
-            *reinterpret_cast<gd4*>(dst + (long)(16 * p) * ld + 16 * rb) = v;
-          }
-        }
-      }
-  }
-  lds_barrier();
-  // no trailing columns: nobody reads the image
-  const int cols16 = (Pr.cols + 15) & ~15;
-  if (cols16 <= jb + 64) return;
-  const int nrb = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) >> 4;
-  build_images(w, nrb, np, V, OPS, tauL);
-  // image -> the node's slot
-  gd4* dstv = reinterpret_cast<gd4*>((gdbl*)Pr.aux + ws_off + (long)(slot0 + blockIdx.x) * IMG_DOUBLES);
-  typedef __attribute__((address_space(3))) d4 ld4;
-  const ld4* srcv = reinterpret_cast<const ld4*>(lds);
-  for (int i = tid; i < IMG_DOUBLES / 4; i += 256) __builtin_nontemporal_store(srcv[i], dstv + i);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Factorisation of a node, second form: the 64 columns as four 16-column SUB-PANELS.  The column steps touch only their
+// Factorisation of a node: the 64 columns as four 16-column SUB-PANELS.  The column steps touch only their
 // own sub-panel (VALU: a third of the work of updating all four at every step), the later sub-panels are brought up to
 // date with the sub-panel's block reflector on the matrix pipes (W0 = V^T C summed over the four waves through LDS,
 // W = T^T W0, C -= V W; C never leaves the registers).  A column is broadcast along its 16-lane row with DPP
@@ -366,7 +97,7 @@ __global__ void __launch_bounds__(256) k_cq_fac(const v2::QrProb* probs, int64_t
 // TREE: the node is a stack of four upper-triangular R factors, reflector j only touches rows <= j of segments 1..3
 // (the zero rows are skipped - 5/8 of the work on average).
 // ------------------------------------------------------------------------------------------------------------------
-// LDS of the second form (68 KB: two node workgroups per CU).  The reflector image itself goes straight to the node's slot in
+// LDS of the node factorisation (68 KB: two node workgroups per CU).  The reflector image itself goes straight to the node's slot in
 // HBM; the LDS keeps the operand images, the exchange areas of the column steps and ONE 16-column panel of the image
 // (leading dimension 17: both MFMA operand shapes read it conflict free) for the in-register update of the later sub-panels.
 constexpr int F_OPS = 0;                    // [10][256] operand images
