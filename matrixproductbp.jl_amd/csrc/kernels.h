@@ -137,9 +137,13 @@ __global__ void kron_kernel(const KronProb* probs, int L) {
   const KronProb P = probs[blockIdx.y];
   const int t = blockIdx.x;
   const int q = P.q, nk = P.nk;
-  int bl[KRON_MAXK], br[KRON_MAXK];
+  int bl[KRON_MAXK], br[KRON_MAXK];               // fixed trip counts + predicates: the arrays stay in registers
   int64_t Bl = 1, Br = 1, ny = 1;
-  for (int k = 0; k < nk; k++) { bl[k] = P.mbond[k][t]; br[k] = P.mbond[k][t + 1]; Bl *= bl[k]; Br *= br[k]; ny *= q; }
+#pragma unroll
+  for (int k = 0; k < KRON_MAXK; k++) {
+    bl[k] = 1; br[k] = 1;
+    if (k < nk) { bl[k] = P.mbond[k][t]; br[k] = P.mbond[k][t + 1]; Bl *= bl[k]; Br *= br[k]; ny *= q; }
+  }
   if (threadIdx.x == 0) {
     P.obond[t] = (int32_t)Bl;
     if (t == L - 1) { P.obond[L] = (int32_t)Br; *P.ologz = 0.0; }       // messages are stored normalised (z = 1)
@@ -152,11 +156,14 @@ __global__ void kron_kernel(const KronProb* probs, int L) {
     int64_t n = r % Br; r /= Br;
     int64_t y = r % ny; const int xi = (int)(r / ny);
     double v = 1.0;
-    for (int k = 0; k < nk; k++) {
-      const int a = (int)(m % bl[k]); m /= bl[k];
-      const int b = (int)(n % br[k]); n /= br[k];
-      const int xk = (int)(y % q); y /= q;
-      v *= P.msg[k][(int64_t)t * P.mstride + a + (int64_t)bl[k] * (b + (int64_t)br[k] * (xk + q * xi))];
+#pragma unroll
+    for (int k = 0; k < KRON_MAXK; k++) {
+      if (k < nk) {
+        const int a = (int)(m % bl[k]); m /= bl[k];
+        const int b = (int)(n % br[k]); n /= br[k];
+        const int xk = (int)(y % q); y /= q;
+        v *= P.msg[k][(int64_t)t * P.mstride + a + (int64_t)bl[k] * (b + (int64_t)br[k] * (xk + q * xi))];
+      }
     }
     O[idx] = v;
   }

@@ -1098,3 +1098,31 @@ def test_generic_factor_limits_are_reported_not_aborted():
     assert "generic factor" in str(ei.value)
     with pytest.raises(M.MPBPError):
         M.periodic_mpbp(M.IndexedBiDiGraph(A), wg, 2, T, phi=phi, max_bond=4)
+
+
+def test_generic_factor_degree4_isolated_node_and_time_dependent_tables_gpu():
+    """Generic factors at the edges of the exhaustive update: a degree-4 hub (product bond 4^3 before the compress), a
+    degree-0 node (belief from phi and the factor alone, no neighbours to sum over) and a factor that changes with time
+    (nt = T + 1 blocks of the table) - all exact on this forest, against enumeration (2^18 trajectories: T = 2) and the
+    oracle's generic update."""
+    T = 2
+    A = np.zeros((6, 6))
+    for k in (1, 2, 3, 4):
+        A[0, k] = A[k, 0] = 1                     # node 0: degree 4; node 5: isolated
+    rng = np.random.default_rng(9)
+    Jt = [0.4 + 0.3 * t for t in range(T + 1)]    # time-dependent coupling
+    h = rng.standard_normal(6) * 0.3
+    phi = [[np.array([0.7, 0.3]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(6)]
+    phi[2][T] = np.array([1.0, 0.0])
+    deg = A.sum(1).astype(int)
+    w = [[M.GenericGlauberFactor([Jt[t] * (1 + 0.1 * k) for k in range(deg[i])], h[i], 1.0) for t in range(T + 1)] for i in range(6)]
+    ow = [[OF.GenericGlauberFactor([Jt[t] * (1 + 0.1 * k) for k in range(deg[i])], h[i], 1.0) for t in range(T + 1)] for i in range(6)]
+    bp = M.mpbp(M.IndexedBiDiGraph(A), w, 2, T, phi=phi, max_bond=4)
+    M.iterate(bp, maxiter=6, svd_trunc=M.TruncThresh(0.0), schedule="colored")
+    obp = O.mpbp(O.IndexedBiDiGraph(A), ow, [2] * 6, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    assert _rel(_flat(M.beliefs(bp)), _flat(exact_marginals(obp, p))) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+    O.iterate(obp, maxiter=6, svd_trunc=OT.TruncThresh(0.0), tol=0.0, shuffle_nodes=False)
+    assert _rel(_flat(M.beliefs(bp)), _flat(O.beliefs(obp))) < 1e-9
