@@ -269,7 +269,7 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
     // JA = R2^T [Rr x k2] (the "L form": about half the sweeps of the R form) WITHOUT accumulating V:
     // the rotated columns are sigma_j u_j.  Columns below 1e-14 ||.||_F are numerically null (they only
     // multiply what the right environment annihilates) and become zero columns of U.
-    const int ldJ = Rr | 1;
+    const int ldJ = JAC_LDS ? (Rr | 1) : ((Rr + 15) & ~15);      // in HBM: columns on 128-byte lines (wg::jac_pair_hbm16)
     double fro2 = 0.0;
     for (int idx = tid; idx < k2 * Rr; idx += WG_THREADS) {
       int r = idx % Rr, c = idx / Rr;            // JA[r, c] = R2[c, r]

@@ -458,7 +458,7 @@ static void plan_cfg(const EngLaunchPlan& pl, int L, mpbp_trunc trunc, EngCfg& c
   cfg.off_T1 = take((int64_t)pl.cap1 * pl.ny1 * pl.q * pl.capout * pl.cap2);
   cfg.off_Nt = take((int64_t)nmax * Bmax);
   cfg.off_Mt = take((int64_t)(r16h((int)Bmax) + 32) * (r16h(nmax) + 16));
-  cfg.off_JA = take((int64_t)(nmax + 1) * nmax);
+  cfg.off_JA = take((int64_t)((nmax + 15) & ~15) * nmax);       // leading dimension of the Jacobi matrix in HBM: engine.h
   cfg.off_JV = take(16);
   const int64_t nA1 = (int64_t)pl.cap1 * pl.cap1 * pl.ny1 * pl.q, nA2 = (int64_t)pl.cap2 * pl.cap2 * pl.ny2 * pl.q;
   const int64_t nE = (int64_t)pl.q * pl.cap2 * pl.ny * pl.cap2 * pl.ny1;

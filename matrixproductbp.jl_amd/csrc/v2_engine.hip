@@ -364,7 +364,7 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
 extern "C" int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps, int32_t* sweeps) {
   ST2CHK(hipSetDevice(device));
   if (m < 1 || n < 1 || n > m || m > 1024) { g_create_error = "need 1 <= n <= m <= 1024"; return MPBP_EINVAL; }
-  const int ldJ = m | 1;
+  const int ldJ = v2::jac_ld(m);
   std::vector<double> JA((size_t)ldJ * n, 0.0);
   double fro2 = 0.0;
   for (int c = 0; c < n; c++) for (int r = 0; r < m; r++) { const double v = A[r + (size_t)m * c]; JA[r + (size_t)ldJ * c] = v; fro2 += v * v; }
@@ -500,7 +500,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
         pp.kc[t + 1] = kp;
         pp.c_doubles = std::max<int64_t>(pp.c_doubles, (int64_t)kp * Bn);
         pp.mt_doubles = std::max<int64_t>(pp.mt_doubles, (int64_t)r32i(r1) * (r16i(Rr) + 16));
-        pp.ja_doubles = std::max<int64_t>(pp.ja_doubles, (int64_t)(Rr | 1) * std::min(r1, Rr));
+        pp.ja_doubles = std::max<int64_t>(pp.ja_doubles, (int64_t)v2::jac_ld(Rr) * std::min(r1, Rr));
         pp.u_doubles = std::max<int64_t>(pp.u_doubles, (int64_t)Rr * kp);
         pp.rows32_max = std::max(pp.rows32_max, r32i(r1)); pp.cols_max = std::max(pp.cols_max, Rr);
       }

@@ -1178,6 +1178,8 @@ __global__ void __launch_bounds__(256) k_scale(const ScaleDesc* descs, EngStats*
   if (blockIdx.x == 0 && threadIdx.x == 0) *D.logc += log(mx);
 }
 
+// leading dimension of the Jacobi matrix in HBM: columns start on 128-byte lines (wg::jac_pair_hbm16)
+__host__ __device__ inline int jac_ld(int m) { return (m + 15) & ~15; }
 struct SvdDesc {
   const double* Mt; double* JA; double* U; double* core; int32_t* obond;   // obond: the output train's bond table
   int32_t ldM, r1, Rr, kc, kp, t, L, kind, mprime, cap_out;
@@ -1198,7 +1200,7 @@ __global__ void __launch_bounds__(512) k_svd_trunc(const SvdDesc* descs, EngStat
   const int tid = threadIdx.x;
   const int Rr = D.Rr, r1 = D.r1, kc = D.kc;
   const int k2 = min(r1, Rr);
-  const int ldJ = Rr | 1;
+  const int ldJ = jac_ld(Rr);
   const gdbl* Mt = (const gdbl*)D.Mt;
   gdbl* JA = (gdbl*)D.JA;
   double fro2 = 0.0;
@@ -1289,7 +1291,7 @@ __global__ void __launch_bounds__(512) k_jac_round(const SvdDesc* descs, int rou
   }
   if (p > q) { const int t_ = p; p = q; q = t_; }
   if (q >= n) return;                                // the dummy player of an odd tournament
-  const int ldJ = m | 1;
+  const int ldJ = jac_ld(m);
   gdbl* ap = (gdbl*)D.JA + (int64_t)ldJ * p;
   gdbl* aq = (gdbl*)D.JA + (int64_t)ldJ * q;
   double x[32], y[32];

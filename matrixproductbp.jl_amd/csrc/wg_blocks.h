@@ -1814,6 +1814,60 @@ __device__ __forceinline__ double jac_pair8(AP ap, AP aq, int sub, double tol, d
   return ga * ga / (al * be);
 }
 
+template <class T> struct jac_in_hbm { static constexpr bool value = false; };
+template <> struct jac_in_hbm<gdbl*> { static constexpr bool value = true; };
+
+// One column pair of a matrix in HBM handled by 8 lanes with 16-byte accesses: lane `sub` holds the row pairs
+// 2 (sub + 8 j), +1, so the eight lanes of a pair read / write one whole 128-byte line per instruction (the columns are
+// 128-byte aligned: lda a multiple of 16).  A round of the HBM-resident Jacobi is bound by the number of lines a CU's L1 can
+// serve (a 160-row column is ten lines, every round touches all columns two to three times); with one row per lane and
+// access every line was requested twice.  Same rotations as the scalar path; the dot products sum the rows in another order.
+__device__ __forceinline__ double jac_pair_hbm16(gdbl* ap, gdbl* aq, int sub, int m, double tol, double nul) {
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) d2_t gd2_t;
+  constexpr int JP = 6;                        // row pairs per lane held in registers at a time (12 rows, as the scalar path)
+  const int npl = (m + 15) >> 4;               // row pairs per lane
+  double al = 0, be = 0, ga = 0;
+  d2_t x[JP], y[JP];
+  auto loadc = [&](int j0) {
+#pragma unroll
+    for (int j = 0; j < JP; j++) {
+      const int r = 2 * (sub + 8 * (j0 + j));
+      const bool ok0 = r < m, ok1 = r + 1 < m;
+      const int rc = ok1 ? r : 2 * sub;        // an in-range, aligned pair (m >= 16 on this path)
+      const d2_t xv = *reinterpret_cast<const gd2_t*>(ap + rc), yv = *reinterpret_cast<const gd2_t*>(aq + rc);
+      x[j] = d2_t{ok0 && ok1 ? xv[0] : 0.0, ok1 ? xv[1] : 0.0};
+      y[j] = d2_t{ok0 && ok1 ? yv[0] : 0.0, ok1 ? yv[1] : 0.0};
+    }
+  };
+  for (int j0 = 0; j0 < npl; j0 += JP) {
+    loadc(j0);
+#pragma unroll
+    for (int j = 0; j < JP; j++) {
+      al += x[j][0] * x[j][0]; be += y[j][0] * y[j][0]; ga += x[j][0] * y[j][0];
+      al += x[j][1] * x[j][1]; be += y[j][1] * y[j][1]; ga += x[j][1] * y[j][1];
+    }
+  }
+  al += dpp64<0x141>(al); be += dpp64<0x141>(be); ga += dpp64<0x141>(ga);
+  al += dpp64<0x4E>(al); be += dpp64<0x4E>(be); ga += dpp64<0x4E>(ga);
+  al += dpp64<0xB1>(al); be += dpp64<0xB1>(be); ga += dpp64<0xB1>(ga);
+  if (!(ga * ga > (tol * tol) * (al * be) && al > nul && be > nul)) return 0.0;
+  double c, s;
+  jac_cs(al, be, ga, c, s);
+  for (int j0 = 0; j0 < npl; j0 += JP) {
+    if (npl > JP) loadc(j0);
+#pragma unroll
+    for (int j = 0; j < JP; j++) {
+      const int r = 2 * (sub + 8 * (j0 + j));
+      if (r + 1 < m) {
+        *reinterpret_cast<gd2_t*>(ap + r) = d2_t{c * x[j][0] - s * y[j][0], c * x[j][1] - s * y[j][1]};
+        *reinterpret_cast<gd2_t*>(aq + r) = d2_t{s * x[j][0] + c * y[j][0], s * x[j][1] + c * y[j][1]};
+      }
+    }
+  }
+  return ga * ga / (al * be);
+}
+
 template <class AP>     // AP = ldbl* (matrix in LDS) or gdbl* (in HBM): typed so that the inner loops are ds_* / global_*
 __device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n, double* V, int ldv, ldbl* red,
                                                     __attribute__((address_space(3))) int* act, int maxsweeps) {
@@ -1849,6 +1903,7 @@ __device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n,
     const int grp = tid >> lg;
     const int rpl = (m + LP - 1) >> lg;   // rows per lane
     const bool exact8 = !V && lg == 3 && m == 8 * rpl && (rpl == 2 || rpl == 4 || rpl == 6 || rpl == 8 || rpl == 10 || rpl == 12);
+    const bool hbm16 = jac_in_hbm<AP>::value && !V && lg == 3 && (m & 1) == 0 && m >= 16 && (lda & 15) == 0;
     double worst = 0.0;                   // largest cos^2 of the angle between two columns met in this sweep
     for (int round = 0; round < ne - 1; round++) {
       for (int pb = 0; pb < npairs; pb += WG_THREADS >> lg) {
@@ -1866,6 +1921,10 @@ __device__ __attribute__((noinline)) int jacobi_rsv(AP A, int lda, int m, int n,
             const int cp = act[p], cq = act[q];
             AP ap = A + (long)lda * cp;
             AP aq = A + (long)lda * cq;
+            if (hbm16) {           // matrix in HBM, even column length, aligned columns: whole lines per access
+              if constexpr (jac_in_hbm<AP>::value) worst = fmax(worst, jac_pair_hbm16(ap, aq, sub, m, tol, nul));
+              continue;
+            }
             if (exact8) {          // the common shapes: 8 lanes per pair, column length a multiple of 8 (wave-uniform)
               double w2 = 0.0;
               switch (rpl) {
