@@ -914,7 +914,22 @@ static int sweep_nodes(mpbp_ctx* c, const int32_t* nodes, int32_t n_nodes, mpbp_
         for (int k : ready) avail[ops[k].out] = 1;
         rem.swap(later);
       }
-      for (int lev = 2; lev <= maxlevel; lev++) { rc = small_level(lev); if (rc != MPBP_OK) return rc; }
+      // the single-wave problems above level 1 (products with the bond-1 init train: dest[z-1], full): by readiness as well -
+      // everything they read exists by now, so they share ONE launch instead of one per level (each launch is a sequential
+      // chain of T + 1 time steps: configs[4] 0.75 s, configs[3] ~0.3 s per level)
+      std::vector<int> srem;
+      for (int k = 0; k < (int)ops.size(); k++) if (is_small(ops[k]) && ops[k].level >= 2) srem.push_back(k);
+      while (!srem.empty()) {
+        std::vector<int> ready, later;
+        for (int k : srem) (avail[ops[k].in1] && avail[ops[k].in2] ? ready : later).push_back(k);
+        if (ready.empty()) return c->fail(MPBP_EINVAL, "internal: cavity dependency graph is not acyclic");
+        EngLaunchPlan pls; pls.q = q; pls.capout = cap; pls.small = true;
+        for (int k : ready) add_problem(pls, ops[k]);
+        rc = launch_engine(c, pls, trunc, false, &ms_orth, &n_orth);
+        if (rc != MPBP_OK) return rc;
+        for (int k : ready) avail[ops[k].out] = 1;
+        srem.swap(later);
+      }
     } else {
       for (int lev = 1; lev <= maxlevel; lev++) {
         EngLaunchPlan plb; plb.q = q; plb.capout = cap;
