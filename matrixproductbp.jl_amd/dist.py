@@ -35,7 +35,8 @@ def node_costs(nbr_ptr, q, max_bond, T, nstates=None):
 #                  single problem advances at the latency of its launch sequence, not at the flop rate.  Levels of different
 #                  hubs of one rank run in the SAME launches, so the rank pays for its deepest node only (max, not sum).
 # RATE_GRID and LEVEL_LATENCY are the least-squares fit of  time = flops / RATE_GRID + levels(z_max) T LEVEL_LATENCY  to the eight
-# measured blocks (245.8 ... 270.3 s, z_max 9 ... 12): residuals within 2 %.
+# measured blocks (245.8 ... 270.3 s, z_max 9 ... 12): residuals within 2 %.  (Fitted before the last step of round 3 - the
+# line-aligned Jacobi of the truncating sweep took ~11 % off a block; the RATIO of the two terms, which is what the cut uses, stands.)
 RATE_WG = 20e12
 RATE_GRID = 18e12
 LEVEL_LATENCY = 30e-3
