@@ -137,6 +137,10 @@ def test_time_model_balances_config2_for_8_ranks_and_memory_plan_fits():
     pred = D.rank_times(list(measured.keys()), work, tail)
     err = np.abs(pred - np.array(list(measured.values()))) / np.array(list(measured.values()))
     assert err.max() < 0.04, dict(zip(measured.keys(), np.round(pred, 1)))
+    # three blocks of the shipped cut re-measured on the round's final build: uniformly ~11 % faster than the model's constants
+    final = {(0, 226): 222.3, (783, 1054): 225.1, (1306, 1558): 234.6}
+    ratio = np.array(list(final.values())) / D.rank_times(list(final.keys()), work, tail)
+    assert ratio.max() / ratio.min() < 1.08 and 0.8 < ratio.mean() < 1.0, ratio
     worst = {}
     for world in (2, 4, 8):
         sh = D.shard_nodes_by_time(ptr, world, work, tail)
