@@ -713,22 +713,36 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
 #pragma unroll
   for (int p = 0; p < 4; p++) w[p] = -w[p];
   // ------------------------------------------------ phase C: C -= sum_p V_p W_p
+  // (the LDS operands of row group rb + 1 are fetched while the MFMAs of row group rb run, as in phase A: fetched right in
+  //  front of their MFMAs, every (row group, sub-panel) waited ~100 cycles for its four reads)
+  double a[4][4], an[4][4];
+  auto fetch = [&](int rb, double (&dst)[4][4]) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      if (tree_skip(TREE, rb, p)) continue;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const ldbl* vb = V + ((p & 1) ? cO[s] : cE[s]) + ((rb < 8) ? 0 : 8192);
+        dst[p][s] = vb[16 * p + 1024 * (rb & 7)];
+      }
+    }
+  };
+  fetch(0, a);
 #pragma unroll
   for (int rb = 0; rb < 16; rb++) {
+    if (rb + 1 < 16) fetch(rb + 1, an);
     d4 acc = C[rb];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       if (tree_skip(TREE, rb, p)) continue;
-      double a[4];
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const ldbl* vb = V + ((p & 1) ? cO[s] : cE[s]) + ((rb < 8) ? 0 : 8192);
-        a[s] = vb[16 * p + 1024 * (rb & 7)];
-      }
-#pragma unroll
-      for (int s = 0; s < 4; s++) acc = mfma(a[s], w[p][s], acc);
+      for (int s = 0; s < 4; s++) acc = mfma(a[p][s], w[p][s], acc);
     }
     if (rb < nrb) __builtin_nontemporal_store(acc, reinterpret_cast<gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) a[p][s] = an[p][s];
     __builtin_amdgcn_sched_barrier(0);
   }
 }
