@@ -35,11 +35,11 @@ def node_costs(nbr_ptr, q, max_bond, T, nstates=None):
 #                  single problem advances at the latency of its launch sequence, not at the flop rate.  Levels of different
 #                  hubs of one rank run in the SAME launches, so the rank pays for its deepest node only (max, not sum).
 # RATE_GRID and LEVEL_LATENCY are the least-squares fit of  time = flops / RATE_GRID + levels(z_max) T LEVEL_LATENCY  to the eight
-# measured blocks (245.8 ... 270.3 s, z_max 9 ... 12): residuals within 2 %.  (Fitted before the last step of round 3 - the
-# line-aligned Jacobi of the truncating sweep took ~11 % off a block; the RATIO of the two terms, which is what the cut uses, stands.)
+# blocks of the shipped cut measured on the round's FINAL build (222.3 ... 235.3 s, z_max 9 ... 12): residuals within 2.2 %.
+# (The same fit on the build before the line-aligned Jacobi of the truncating sweep gave 18.0 TFLOP/s and 30 ms.)
 RATE_WG = 20e12
-RATE_GRID = 18e12
-LEVEL_LATENCY = 30e-3
+RATE_GRID = 18.6e12
+LEVEL_LATENCY = 19.5e-3
 
 
 def node_times(nbr_ptr, q, max_bond, T, nstates=None, grid=None):
