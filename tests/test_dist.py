@@ -199,3 +199,22 @@ def test_allgather_slots_through_the_c_abi_rccl_world1():
     assert L.mpbp_allgather_slots(bp._h, comm, 0, 2, g.E) == -1          # world * slots_per_rank must equal n_slots
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+def test_shard_nodes_by_time_edge_cases():
+    """Contiguous cover for any world size: fewer nodes than ranks (empty blocks allowed), no tails at all (regular graph:
+    the cut reduces to the equal-work cut), one dominant hub (it gets a rank of its own)."""
+    from mpbp_amd import dist as D
+    for N, world in ((3, 8), (1, 2), (10, 3), (64, 8)):
+        ptr = np.arange(N + 1) * 3
+        work = np.ones(N); tail = np.zeros(N)
+        sh = D.shard_nodes_by_time(ptr, world, work, tail)
+        assert len(sh) == world and sh[0][0] == 0 and sh[-1][1] == N
+        assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(sh[:-1], sh[1:]))
+        t = D.rank_times(sh, work, tail)
+        assert t.max() == -(-N // world)                 # the slowest rank is as light as a contiguous cut allows
+    work = np.ones(40); tail = np.zeros(40); work[17] = 25.0; tail[17] = 30.0
+    sh = D.shard_nodes_by_time(np.arange(41), 4, work, tail)
+    hub = [r for r, (lo, hi) in enumerate(sh) if lo <= 17 < hi][0]
+    assert sh[hub][1] - sh[hub][0] <= 3                  # the hub's rank holds (almost) nothing else
+    assert D.rank_times(sh, work, tail).max() <= 55.0 + 1e-9 + 2.0

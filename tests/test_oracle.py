@@ -382,3 +382,25 @@ def test_periodic_oracle_is_exact_on_the_reference_tree():
     pb, _ = OP.pair_beliefs(bp)
     pex = exact_pair_marginals(bp, p)
     assert max(np.abs(np.array(pb[e][t]) - pex[e][t]).max() for e in range(g.E) for t in range(T + 1)) < 1e-9
+
+
+def test_generic_factor_tables_of_the_host_mirror_match_the_functor():
+    """`BPFactor.generic_table` (the dense table `mpbp_set_generic_factor` takes: w[x', x, x_1..x_deg], first index fastest)
+    against direct evaluation of the oracle's functor, for GenericGlauberFactor and a GenericFactor-wrapped SIS factor; and
+    `glauber_factors` picks the generic type exactly when the reference does (src/Models/glauber/glauber_bp.jl:121-142)."""
+    import itertools
+    import mpbp_amd as M
+    from oracle import factors as OF
+    cases = [(M.GenericGlauberFactor([0.3, -0.7, 1.1], 0.2, 0.9), OF.GenericGlauberFactor([0.3, -0.7, 1.1], 0.2, 0.9), 3),
+             (M.GenericFactor(M.SISFactor(0.3, 0.2, 0.05)), OF.GenericFactor(OF.SISFactor(0.3, 0.2, 0.05)), 2)]
+    for w, ow, deg in cases:
+        tab = w.generic_table(deg, 2).reshape((2, 2) + (2,) * deg, order="F")
+        for xs in itertools.product(range(2), repeat=deg):
+            for x in range(2):
+                for xn in range(2):
+                    assert abs(tab[(xn, x) + xs] - ow(xn + 1, [v + 1 for v in xs], x + 1)) < 1e-15
+        assert np.allclose(tab.sum(axis=0), 1.0)              # a transition probability
+    J = np.array([[0, 0.3, 0], [0.3, 0, -0.7], [0, -0.7, 0]], float)
+    assert all(isinstance(wi[0], M.GenericGlauberFactor) for wi in M.glauber_factors(J != 0, J, np.zeros(3), 1.0, 2))
+    J2 = np.where(J != 0, 0.5, 0.0)
+    assert all(isinstance(wi[0], M.HomogeneousGlauberFactor) for wi in M.glauber_factors(J2 != 0, J2, np.zeros(3), 1.0, 2))
