@@ -187,6 +187,9 @@ int mpbp_reset_messages(mpbp_ctx* ctx);
  * other work resident (a second process, another stream of the caller) an arrival counter can time out: the kernel then
  * leaves its panel untouched, the library repeats the batch with one launch per column step and keeps the context in
  * that mode - slower, never wrong.  MPBP_DEBUG_NO_COOP_PANEL=1 starts in that mode (ranks that share a device).
+ * Contexts on ONE device share two internal CU-masked streams (the look-ahead of the batched QR; created on first use,
+ * destroyed when the last context of the device is destroyed): one host thread per context is fine, but calls into
+ * different contexts of the same device must not run concurrently.
  */
 int mpbp_sweep(mpbp_ctx* ctx, const int32_t* nodes, int32_t n_nodes, mpbp_trunc trunc, double damp,
                mpbp_stats* stats /* may be NULL */);
@@ -241,6 +244,11 @@ int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, const double
  * the gauge sweep (csrc/v2_kernels.h); R: [nprob][min(rows,cols) x cols]; force_tall: column-step panels always. */
 int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t cols, int32_t nprob, int32_t force_tall,
                              const double* A, double* R, double* ms_out);
+/* a SEQUENCE of single matrices rows[s] x cols through the same batched QR on ONE shared scratch sized for the largest
+ * (what consecutive time steps of a gauge sweep do); A, R concatenated; path[s] = the form taken (1 communication-
+ * avoiding tree, 2 look-ahead panels, 0 launch per panel) */
+int mpbp_selftest_qr_batched_seq(int32_t device, int32_t nshape, const int32_t* rows, int32_t cols, const double* A,
+                                 double* R, int32_t* path);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpbp_hip.so")
 SOURCES = ["mpbp_hip.hip", "v2_engine.hip"]
-HEADERS = ["kernels.h", "engine.h", "engine_types.h", "wg_blocks.h", "wg_common.h", "ctx.h", "v2_kernels.h", "v2_engine.h",
-           os.path.join("..", "..", "include", "mpbp_hip.h")]
+
+
+def headers():
+    """every header a translation unit can include: all of csrc/*.h plus the public C ABI header (a stale-object check that
+    lists headers by hand silently misses new ones - round-3 review item 6)"""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "mpbp_hip.h")]
+
 
 MPBP_TRUNC_THRESH, MPBP_TRUNC_BOND, MPBP_TRUNC_BOND_MAX, MPBP_TRUNC_BOND_THRESH = 0, 1, 2, 3
 
@@ -50,13 +56,13 @@ EXPORTS = ["mpbp_create", "mpbp_destroy", "mpbp_last_error", "mpbp_slab_layout",
            "mpbp_set_factor", "mpbp_set_generic_factor", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
            "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_get_belief_train", "mpbp_pair_beliefs",
            "mpbp_free_energy", "mpbp_logz", "mpbp_allgather_slots", "mpbp_twovar_marginals", "mpbp_set_profiling", "mpbp_phase_profile", "mpbp_selftest_gemm", "mpbp_selftest_qr", "mpbp_selftest_qr_bench",
-           "mpbp_selftest_jacobi_bench", "mpbp_selftest_svd", "mpbp_selftest_qr_batched", "mpbp_selftest_jacobi_grid"]
+           "mpbp_selftest_jacobi_bench", "mpbp_selftest_svd", "mpbp_selftest_qr_batched", "mpbp_selftest_qr_batched_seq", "mpbp_selftest_jacobi_grid"]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per source
     (compiled concurrently, only when stale), then one link."""
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hdrs = headers()
     flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-fPIC"]
     objs, procs = [], []
     for s in SOURCES:
@@ -133,6 +139,7 @@ def lib():
     L.mpbp_selftest_svd.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
     L.mpbp_selftest_jacobi_grid.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, C.c_int32, ip]
     L.mpbp_selftest_qr_batched.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
+    L.mpbp_selftest_qr_batched_seq.argtypes = [C.c_int32, C.c_int32, ip, C.c_int32, dp, dp, ip]
     _lib = L
     return L
 

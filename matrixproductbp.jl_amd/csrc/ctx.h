@@ -16,10 +16,13 @@
 
 extern thread_local std::string g_create_error;
 
+// On failure the call is abandoned - but host vectors of the caller may still be the source of an asynchronous copy in
+// flight on the context's stream, so the stream is drained before the early return lets them die (round-3 advisor).
 #define HIPCHK(ctx, call)                                                                         \
   do {                                                                                            \
     hipError_t e_ = (call);                                                                       \
     if (e_ != hipSuccess) {                                                                       \
+      if ((ctx)->stream) (void)hipStreamSynchronize((ctx)->stream);                               \
       return (ctx)->fail(MPBP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     }                                                                                             \
   } while (0)
@@ -85,6 +88,7 @@ struct mpbp_ctx {
   std::vector<int64_t> pyy_base;   // per node: offset of prob_yy blob
   Arena arena, scratch, v2arena;   // work trains of a sweep / engine slots + launch records / batched gauge sweep
   int num_cu = 256;
+  bool dev_held = false;        // v2_device_acquire done (released in mpbp_destroy)
   bool no_coop_panel = false;   // set after a cooperative panel launch timed out: the column steps then run as separate launches
   int profiling = 0;            // 0 off, 1 HIP-event timing of the cavity launches, 2 also the in-kernel phase timers
   std::string err;

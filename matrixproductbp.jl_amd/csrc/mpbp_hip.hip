@@ -42,6 +42,7 @@ extern "C" int mpbp_create(mpbp_ctx** out, const mpbp_desc* d) {
   if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); delete c; return MPBP_EHIP; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  v2_device_acquire(c->device); c->dev_held = true;
   auto bail = [&](const char* what, hipError_t er) { g_create_error = std::string(what) + ": " + hipGetErrorString(er); mpbp_destroy(c); return er == hipErrorOutOfMemory ? MPBP_ENOMEM : MPBP_EHIP; };
   if (d->stream) c->stream = (hipStream_t)d->stream;
   else { if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e); c->own_stream = true; }
@@ -107,6 +108,7 @@ extern "C" void mpbp_destroy(mpbp_ctx* c) {
                   (void*)c->d_one, (void*)c->d_ones, (void*)c->d_ident, (void*)c->d_tab, (void*)c->arena.base, (void*)c->scratch.base, (void*)c->v2arena.base})
     if (p) hipFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  if (c->dev_held) v2_device_release(c->device);
   delete c;
 }
 
@@ -172,6 +174,17 @@ extern "C" int mpbp_set_generic_factor(mpbp_ctx* c, int32_t node, int32_t deg, i
   if (deg > KRON_MAXK) return c->fail(MPBP_EUNSUPPORTED, "generic factor of degree %d: the exhaustive update enumerates q^degree neighbour states, at most degree %d is supported", deg, KRON_MAXK);
   int64_t sz = (int64_t)c->q * c->q;
   for (int k = 0; k < deg; k++) { sz *= c->q; if (sz > ((int64_t)1 << 26)) return c->fail(MPBP_EUNSUPPORTED, "generic factor table of node %d is too large", node); }
+  {
+    // the limit of the exhaustive update on the device, reported where the factor is set (construction of the host
+    // mirror), not at the first sweep: the embeddings are compressed by one 512-thread workgroup each, whose register
+    // panel holds 2048 rows of Y_t, and the work trains are sized by the bond CAP
+    int64_t bm = c->ct_factor(), bb = c->ct_factor();
+    for (int k = 0; k < deg; k++) { if (k < deg - 1) bm = std::min<int64_t>(bm * c->cap, (int64_t)1 << 40); bb = std::min<int64_t>(bb * c->cap, (int64_t)1 << 40); }
+    if (deg > 0 && (bm * c->q * c->q > 2048 || bb * c->q > 2048))
+      return c->fail(MPBP_EUNSUPPORTED, "node %d: generic factor of degree %d with max_bond %d needs product bonds %lld / %lld (limit: q^2 x bond <= 2048 rows); "
+                     "the exhaustive update is exponential in the degree - use a RecursiveBPFactor model, a smaller max_bond or fewer neighbours",
+                     node, deg, c->cap, (long long)bm, (long long)bb);
+  }
   NodeFactor& f = c->fac[node];
   f = NodeFactor{};
   f.set = true; f.generic = true; f.deg = deg; f.nt = nt;

@@ -14,3 +14,8 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
 
 // Bond tables (bond1, bond2; L+1 entries each) of probs[0 .. n) -> host, [n][2][L+1].  Synchronises the stream.
 int v2_gather_bonds(mpbp_ctx* c, const EngProb* probs, int n, std::vector<int32_t>& hb);
+
+// Per-device shared state of the batched QR (the look-ahead's two CU-masked streams + six events): every context holds a
+// reference from mpbp_create to mpbp_destroy; the last release destroys them (nothing is left for static destructors).
+void v2_device_acquire(int dev);
+void v2_device_release(int dev);

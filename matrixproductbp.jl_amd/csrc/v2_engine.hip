@@ -13,6 +13,7 @@ namespace v512 {
 #include "cq_kernels.h"
 #include "ctx.h"
 #include "v2_engine.h"
+#include <mutex>
 
 namespace {
 
@@ -43,11 +44,30 @@ struct LookAhead {
   hipEvent_t e_in = nullptr, e_a[2] = {nullptr, nullptr}, e_b = nullptr, e_out_a = nullptr, e_out_b = nullptr;
   bool ok = false, tried = false;
 };
+// Per-device state shared by every context (and self test) of the process on that device: the two CU-masked streams and
+// six events of the look-ahead, and the "function attributes are set" flag.  Reference counted: mpbp_create /
+// mpbp_selftest_qr_batched* acquire, mpbp_destroy / the end of the self test release, and the LAST release destroys the
+// streams and events - so nothing of ours is alive when static destructors (and a profiler's finaliser) run at exit
+// (round-3 review item 5).  The mutex makes creation safe for contexts of several host threads on one device; the streams
+// themselves are used by one qr_batch at a time (include/mpbp_hip.h: contexts on one device share them - calls into
+// different contexts of one device must not overlap in time).
+struct DeviceShared { std::mutex mu; int refs = 0; bool attrs = false; LookAhead la; };
+constexpr int MAX_DEV = 16;
+static DeviceShared g_dev[MAX_DEV];
+
+static void la_destroy(LookAhead& l) {
+  if (l.sa) { (void)hipStreamSynchronize(l.sa); (void)hipStreamDestroy(l.sa); }
+  if (l.sb) { (void)hipStreamSynchronize(l.sb); (void)hipStreamDestroy(l.sb); }
+  for (hipEvent_t e : {l.e_in, l.e_a[0], l.e_a[1], l.e_b, l.e_out_a, l.e_out_b}) if (e) (void)hipEventDestroy(e);
+  l = LookAhead{};
+}
 static LookAhead* lookahead_streams() {
-  static LookAhead la[16];
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  LookAhead& l = la[dev];
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  DeviceShared& D = g_dev[dev];
+  std::lock_guard<std::mutex> lk(D.mu);
+  if (D.refs <= 0) return nullptr;             // nobody holds the device: there would be no one to release the streams
+  LookAhead& l = D.la;
   if (!l.tried) {
     l.tried = true;
     if (getenv("MPBP_DEBUG_NO_LOOKAHEAD")) return nullptr;
@@ -57,13 +77,26 @@ static LookAhead* lookahead_streams() {
     if (ncu < 2 * LA_RESERVED) return nullptr;
     std::vector<uint32_t> mb(words, 0u), ma(words, 0u);
     for (int i = 0; i < ncu; i++) (i < LA_RESERVED ? mb : ma)[i / 32] |= 1u << (i % 32);
-    if (hipExtStreamCreateWithCUMask(&l.sa, words, ma.data()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipExtStreamCreateWithCUMask(&l.sb, words, mb.data()) != hipSuccess) { (void)hipGetLastError(); hipStreamDestroy(l.sa); return nullptr; }
+    if (hipExtStreamCreateWithCUMask(&l.sa, words, ma.data()) != hipSuccess) { (void)hipGetLastError(); l.sa = nullptr; return nullptr; }
+    if (hipExtStreamCreateWithCUMask(&l.sb, words, mb.data()) != hipSuccess) { (void)hipGetLastError(); l.sb = nullptr; la_destroy(l); l.tried = true; return nullptr; }
     bool ev = true;
     for (hipEvent_t* e : {&l.e_in, &l.e_a[0], &l.e_a[1], &l.e_b, &l.e_out_a, &l.e_out_b}) ev = ev && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     l.ok = ev;
   }
   return l.ok ? &l : nullptr;
+}
+// dynamic-LDS limits of the batched QR's kernels: an attribute belongs to the (function, device) pair, so it is set once
+// per device (it used to be set 6-7 times per qr_batch call, ~400 intercepted API calls per gauge sweep)
+static void set_func_attrs_once() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = -1;
+  if (dev >= 0) { std::lock_guard<std::mutex> lk(g_dev[dev].mu); if (g_dev[dev].attrs) return; g_dev[dev].attrs = true; }
+  hipFuncSetAttribute((const void*)v2::k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2::fpanel_lds_bytes(3));
+  hipFuncSetAttribute((const void*)cq::k_cq_upd<512>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
+  hipFuncSetAttribute((const void*)cq::k_cq_upd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
+  hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
+  hipFuncSetAttribute((const void*)cq::k_cq_fac2x2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
+  hipFuncSetAttribute((const void*)cq::k_cq_updfac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
 }
 
 // Launch sequence of one R-only QR over a batch whose dimensions `dims` are known on the host.
@@ -74,8 +107,9 @@ static LookAhead* lookahead_streams() {
 // 7200 x 900 x 128: 82.5 against 73.6 ms; without disjoint CUs the chains' VALU-bound kernels share SIMDs with MFMA streams
 // and run at a third of their speed, profiles/r03_dp_pipe_probe.txt.)
 int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims>& dims, const v2::AuxLay& lay,
-             bool force_tall, int* coop_err = nullptr, int coop_max_wgs = 128, int64_t aux2 = 0) {
+             bool force_tall, int* coop_err = nullptr, int coop_max_wgs = 128, int64_t aux2 = 0, int ncu = 256, int* path = nullptr) {
   const int P = (int)dims.size();
+  if (path) *path = 0;             // which form ran (self tests): 1 communication-avoiding, 2 look-ahead, 0 launch per panel
   if (P == 0) return 0;
   int kmax_max = 0, kmax_min = 1 << 30, rows32_max = 0, cols_max = 0;
   for (const QrDims& d : dims) {
@@ -84,8 +118,7 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
   }
   const int nchunk = (rows32_max + v2::CH - 1) / v2::CH;
   if (nchunk > lay.nchunk) return -1;
-  // per call: the attribute belongs to the (function, device) pair, and a process may hold contexts on several devices
-  hipFuncSetAttribute((const void*)v2::k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2::fpanel_lds_bytes(3));
+  set_func_attrs_once();
   static const bool no_coop = getenv("MPBP_DEBUG_NO_COOP_PANEL") != nullptr;
 
   // ---- the panel chain of block jb (4 panels: in-block update, column steps, Gram, T) on stream s with scratch layout L
@@ -149,12 +182,12 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
 
   // ---- look-ahead: uniform large problems only (every block has four full panels for every problem, the cooperative
   //      panel kernel fits the reserved CUs, the trailing matrix is wide enough to have a part 2)
-  LookAhead* la = (aux2 > 0 && coop_err && !no_coop && !getenv("MPBP_DEBUG_NO_COOP_TRAIL")) ? lookahead_streams() : nullptr;
-  const bool la_shape = la && (int64_t)nchunk * P <= LA_MAX_WGS && rows32_max > 2 * v2::CH && kmax_min == kmax_max;
-  const v2::AuxLay lay2[2] = {lay, v2::shift_auxlay(lay, aux2)};
+  const v2::AuxLay lay2[2] = {lay, v2::second_auxlay(lay, aux2)};
 
   // ---- communication-avoiding form (cq_kernels.h): tall problems, every one with rows >= cols; the node slots live in
-  //      the per-problem scratch behind the fixed header (lay.part on: partial products / Grams / W0 of the other form)
+  //      the per-problem scratch behind the fixed headers of BOTH copies (which sit together at the front: lay.part on =
+  //      the partial products / Grams / W0 of the other form, first and second copy back to back), so a CAQR call never
+  //      touches the arrival counters a later look-ahead call on the same scratch relies on (round-3 advisor)
   {
     static const bool no_cq = getenv("MPBP_DEBUG_NO_CAQR") != nullptr;
     static const int cq_min_rows = [] { const char* e = getenv("MPBP_CQ_MIN_ROWS"); return e ? atoi(e) : v2::CH; }();
@@ -164,12 +197,6 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
     for (int n = (rows32_max + 255) / 256;; n = (n + 3) / 4) { slots += n; if (n == 1) break; }
     const int64_t ws_off = lay.part;
     if (!no_cq && !force_tall && aux2 > 0 && tall_all && rows32_max > cq_min_rows && ws_off + slots * cq::IMG_DOUBLES <= 2 * aux2) {
-      hipFuncSetAttribute((const void*)cq::k_cq_upd<512>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
-      hipFuncSetAttribute((const void*)cq::k_cq_upd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
-      hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
-      hipFuncSetAttribute((const void*)cq::k_cq_fac2x2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
-      int ncu = 256;
-      { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; }
       // One stream, one launch after the other.  Measured and dropped (round 3): (a) the upper-level factorisations of a
       // single problem on a CU-masked stream beside the updates - the 20-40 us per event hand-over and the CUs taken from
       // the updates cost what the overlap gained (16384 x 4096: 43.9 against 44.4 ms at the time); (b) the batch cut into
@@ -177,7 +204,6 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       // ones: 6400 x 1600 x 16 26.9 -> 28.0 / 34.5 ms, 7200 x 900 x 128 69.9 -> 67.1 / 71.6 ms.
       // Per block: F_0, then one launch per level with the update U_l and the next level's factorisation F_{l+1} (k_cq_updfac).
       static const bool no_fuse = getenv("MPBP_DEBUG_CQ_NOFUSE") != nullptr;
-      hipFuncSetAttribute((const void*)cq::k_cq_updfac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
       const int cols16_max = r16i(cols_max);
       // tiles per workgroup: one tile per wave and four-wave workgroups for the small upper levels; else the number of tile
       // groups with the fewest (rounds over the CUs) x (time of a workgroup: ~12 us of image load + 6.2 us per tile, measured
@@ -226,9 +252,15 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
           slot += n;
         }
       }
+      if (path) *path = 1;
       return hipGetLastError() == hipSuccess ? 0 : -2;
     }
   }
+  // (the streams are created on first use - only when a batch has the look-ahead's shape, after the tree form declined)
+  const bool la_cand = aux2 > 0 && coop_err && !no_coop && !getenv("MPBP_DEBUG_NO_COOP_TRAIL") &&
+                       (int64_t)nchunk * P <= LA_MAX_WGS && rows32_max > 2 * v2::CH && kmax_min == kmax_max;
+  LookAhead* la = la_cand ? lookahead_streams() : nullptr;
+  const bool la_shape = la != nullptr;
   bool la_on = false;
   int la_par = 0;
   auto la_leave = [&]() {
@@ -245,6 +277,7 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
     const int ntile4 = cols_max > jb + 64 ? (cols_max - jb - 64 + 15) / 16 : 0;
     if (la_shape && tall && npmax == 4 && kmax_min - jb >= 64 && ntile4 > 8 && rows32_max - jb > 2 * v2::CH) {
       const bool first = !la_on;
+      if (path) *path = 2;
       if (first) {
         hipEventRecord(la->e_in, st);
         hipStreamWaitEvent(la->sa, la->e_in, 0); hipStreamWaitEvent(la->sb, la->e_in, 0);
@@ -304,6 +337,19 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
 
 }  // namespace
 
+void v2_device_acquire(int dev) {
+  if (dev < 0 || dev >= MAX_DEV) return;
+  std::lock_guard<std::mutex> lk(g_dev[dev].mu);
+  g_dev[dev].refs++;
+}
+void v2_device_release(int dev) {
+  if (dev < 0 || dev >= MAX_DEV) return;
+  DeviceShared& D = g_dev[dev];
+  std::lock_guard<std::mutex> lk(D.mu);
+  if (D.refs > 0 && --D.refs == 0) { int cur = 0; (void)hipGetDevice(&cur); (void)hipSetDevice(dev); la_destroy(D.la); (void)hipSetDevice(cur); }
+}
+namespace { struct DeviceHold { int dev; explicit DeviceHold(int d) : dev(d) { v2_device_acquire(d); } ~DeviceHold() { v2_device_release(dev); } }; }
+
 // ================================================================================================
 // self test: nprob independent rows x cols matrices through the batched QR; R[p] = [kmax x cols] (ld kmax)
 // ================================================================================================
@@ -314,6 +360,7 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
                                         const double* A, double* R, double* ms_out) {
   ST2CHK(hipSetDevice(device));
   if (rows < 1 || cols < 1 || nprob < 1) { g_create_error = "bad shape"; return MPBP_EINVAL; }
+  DeviceHold hold(device);
   const int ld = r32i(rows), c16 = r16i(cols) + 16, kmax = std::min(rows, cols);
   const size_t per = (size_t)ld * c16;
   const int nchunk = (ld + v2::CH - 1) / v2::CH, ntile = c16 / 16;
@@ -336,12 +383,15 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
     dims[p] = QrDims{rows, cols, kmax};
   }
   ST2CHK(hipMemcpy(dP, hp.data(), sizeof(v2::QrProb) * nprob, hipMemcpyHostToDevice));
+  (void)lookahead_streams();          // a context creates them once in its life: keep that out of the timed region
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, 0);
   int* dErr = nullptr;
   ST2CHK(hipMalloc(&dErr, sizeof(int)));
   ST2CHK(hipMemset(dErr, 0, sizeof(int)));
-  const int rc = qr_batch(0, dP, dims, lay, force_tall != 0, dErr, 128, (int64_t)auxd);
+  int ncu = 256;
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) ncu = pr.multiProcessorCount; }
+  const int rc = qr_batch(0, dP, dims, lay, force_tall != 0, dErr, 128, (int64_t)auxd, ncu);
   hipEventRecord(e1, 0);
   ST2CHK(hipDeviceSynchronize());
   if (rc != 0) { g_create_error = "qr_batch launch failed"; return MPBP_EHIP; }
@@ -357,6 +407,55 @@ extern "C" int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t co
   }
   hipFree(dY); hipFree(dAux); hipFree(dP);
   return MPBP_OK;
+}
+
+// self test: ONE matrix per call, the calls of a sequence sharing one scratch sized for the largest (as the time steps of a
+// gauge sweep do): rows[s] x cols, A / R concatenated; path[s] = the form qr_batch took (1 communication-avoiding, 2
+// look-ahead, 0 launch per panel).  Pins that a communication-avoiding call leaves the arrival counters of a later
+// look-ahead call intact (round-3 advisor: its node slots used to run over the second scratch copy's header).
+extern "C" int mpbp_selftest_qr_batched_seq(int32_t device, int32_t nshape, const int32_t* rows, int32_t cols, const double* A, double* R, int32_t* path) {
+  ST2CHK(hipSetDevice(device));
+  if (nshape < 1 || cols < 1 || !rows) { g_create_error = "bad shape"; return MPBP_EINVAL; }
+  DeviceHold hold(device);
+  int rmax = 0;
+  for (int s = 0; s < nshape; s++) { if (rows[s] < 1) { g_create_error = "bad shape"; return MPBP_EINVAL; } rmax = std::max(rmax, rows[s]); }
+  const int ldmax = r32i(rmax), c16 = r16i(cols) + 16;
+  const int nchunk = (ldmax + v2::CH - 1) / v2::CH, ntile = c16 / 16;
+  const v2::AuxLay lay = v2::make_auxlay(nchunk, ntile);
+  const size_t auxd = (size_t)v2::auxlay_doubles(nchunk, ntile);
+  double *dY = nullptr, *dAux = nullptr; v2::QrProb* dP = nullptr; int* dErr = nullptr;
+  ST2CHK(hipMalloc(&dY, sizeof(double) * (size_t)ldmax * c16));
+  ST2CHK(hipMalloc(&dAux, sizeof(double) * 2 * auxd));
+  ST2CHK(hipMalloc(&dP, sizeof(v2::QrProb)));
+  ST2CHK(hipMalloc(&dErr, sizeof(int)));
+  ST2CHK(hipMemset(dAux, 0, sizeof(double) * 2 * auxd));                 // once, as v2_gauge_sweep does
+  ST2CHK(hipMemset(dErr, 0, sizeof(int)));
+  int ncu = 256;
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) ncu = pr.multiProcessorCount; }
+  std::vector<double> Y((size_t)ldmax * c16);
+  size_t aoff = 0, roff = 0;
+  int rc_all = MPBP_OK;
+  for (int s = 0; s < nshape && rc_all == MPBP_OK; s++) {
+    const int m = rows[s], ld = r32i(m), kmax = std::min(m, cols);
+    std::fill(Y.begin(), Y.end(), 0.0);
+    for (int j = 0; j < cols; j++) for (int i = 0; i < m; i++) Y[i + (size_t)ld * j] = A[aoff + i + (size_t)m * j];
+    ST2CHK(hipMemcpy(dY, Y.data(), sizeof(double) * (size_t)ld * c16, hipMemcpyHostToDevice));
+    const v2::QrProb hp{dY, dAux, ld, m, cols, kmax};
+    ST2CHK(hipMemcpy(dP, &hp, sizeof hp, hipMemcpyHostToDevice));
+    std::vector<QrDims> dims{QrDims{m, cols, kmax}};
+    int pth = 0;
+    const int rc = qr_batch(0, dP, dims, lay, false, dErr, ncu * 3 / 4, (int64_t)auxd, ncu, &pth);
+    ST2CHK(hipDeviceSynchronize());
+    if (path) path[s] = pth;
+    int herr = 0; ST2CHK(hipMemcpy(&herr, dErr, sizeof(int), hipMemcpyDeviceToHost));
+    if (rc != 0) { g_create_error = "qr_batch launch failed"; rc_all = MPBP_EHIP; }
+    else if (herr) { g_create_error = "cooperative panel: an arrival counter timed out"; rc_all = MPBP_EHIP; }
+    ST2CHK(hipMemcpy(Y.data(), dY, sizeof(double) * (size_t)ld * c16, hipMemcpyDeviceToHost));
+    for (int j = 0; j < cols; j++) for (int i = 0; i < kmax; i++) R[roff + i + (size_t)kmax * j] = (j >= i) ? Y[i + (size_t)ld * j] : 0.0;
+    aoff += (size_t)m * cols; roff += (size_t)kmax * cols;
+  }
+  hipFree(dY); hipFree(dAux); hipFree(dP); hipFree(dErr);
+  return rc_all;
 }
 
 // self test of the multi-launch Jacobi (k_jac_round / k_jac_check): A [m x n] (ld m|1 inside) -> column norms after
@@ -612,10 +711,8 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     HIPCHK(c, hipMemcpyAsync(bf[i].lfoff, htab.data() + (size_t)i * (L + 1) * 12, (size_t)(L + 1) * 12, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));     // the host vectors go out of scope below only after the loop, but keep it simple
   hipLaunchKernelGGL(v2::k_set_one, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SetOne*)done, P);
-  for (int i = 0; i < P; i++) {                                                       // counters, T/S, slots of both scratch copies
-    HIPCHK(c, hipMemsetAsync(bf[i].aux, 0, sizeof(double) * (size_t)lay.part, st));
-    HIPCHK(c, hipMemsetAsync(bf[i].aux + auxd, 0, sizeof(double) * (size_t)lay.part, st));
-  }
+  for (int i = 0; i < P; i++)                                                         // counters, T/S of both scratch copies (the two headers)
+    HIPCHK(c, hipMemsetAsync(bf[i].aux, 0, sizeof(double) * (size_t)(2 * v2::AUX_HDR), st));
   // cooperative panels only while no launch of this context has timed out (launch_engine repeats a failed batch without them)
   int* coop_err = c->no_coop_panel ? nullptr : c->d_counter + 8;
   HIPCHK(c, hipMemsetAsync(c->d_counter + 8, 0, sizeof(int), st));
@@ -638,7 +735,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN1 + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dg1 + o));
     hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
     hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxN2 + 127) / 128), P * q), dim3(512), 0, st, (const v2::GemmDesc*)(dg2 + o * q));
-    if (qr_batch(st, dq + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4, auxd) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (qr_batch(st, dq + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4, auxd, c->num_cu) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
     const int gw = std::min(256, std::max(1, (colsm + 3) / 4));
     hipLaunchKernelGGL(v2::k_maxabs, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), lay);
     hipLaunchKernelGGL(v2::k_lf_write, dim3(gw, P), dim3(256), 0, st, (const v2::QrProb*)(dq + o), (const v2::LfDesc*)(dl + o), lay);
@@ -772,7 +869,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       hipLaunchKernelGGL(v2::k_zero_pads, dim3(std::min(256, std::max(1, rows32m / 8)), P), dim3(256), 0, st, (const v2::QrProb*)(dq2 + o), lay);
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNm + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dmt + o));
       tm.end(1); tm.begin();
-      if (qr_batch(st, dq2 + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4, auxd) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
+      if (qr_batch(st, dq2 + o, dims, lay, force_tall, coop_err, c->num_cu * 3 / 4, auxd, c->num_cu) != 0) return c->fail(MPBP_EHIP, "batched QR launch failed: %s", hipGetErrorString(hipGetLastError()));
       // the SVD of the triangular factor: inside one workgroup, or - factors of several hundred columns - as rounds of
       // rotations over the grid (659 launches per sweep at 660 columns: 20+ workgroups rotate at once, a one-workgroup
       // tournament of that size takes 0.3 s per time step)

@@ -39,6 +39,12 @@ struct AuxLay {
   int32_t nchunk;                 // partial slots per tile in w0 = nchunk * 4 (row sub-chunks of the in-block updates)
   int64_t T, S, tau, piv, mx, bar, part, gram, w0;
 };
+// Per-problem scratch = TWO copies of this layout (the look-ahead of qr_batch: block k+1's panel factorisation writes its
+// T / S / partial products while block k's trailing update still reads its own).  The two fixed-size HEADERS (T .. bar,
+// AUX_HDR doubles each; zeroed once per gauge sweep, `bar` re-zeroed by k_build_T after every panel) sit together at the
+// front, the two bodies (part, gram, w0) behind them:   [hdr 0 | hdr 1 | body 0 | body 1],  2 * auxlay_doubles in all.
+// The communication-avoiding QR keeps its node slots in [a.part, 2 * auxlay_doubles) - both bodies, neither header.
+constexpr int64_t AUX_HDR = 4 * 256 + 6 * 256 + 64 + 256 + 16 + 16;
 __host__ __device__ inline AuxLay make_auxlay(int nchunk, int ntile) {
   AuxLay a; a.nchunk = nchunk;
   int64_t o = 0;
@@ -48,20 +54,22 @@ __host__ __device__ inline AuxLay make_auxlay(int nchunk, int ntile) {
   a.piv = o; o += 256;
   a.mx = o; o += 16;
   a.bar = o; o += 16;            // 17 int32 arrival counters of the cooperative column steps (+ padding)
+  o += AUX_HDR;                  // the second copy's header
   a.part = o; o += (int64_t)nchunk * 256;
   a.gram = o; o += (int64_t)nchunk * GSUB * 4 * 256;
   a.w0 = o; o += (int64_t)ntile * nchunk * 4 * 4 * 256;
   (void)o;
   return a;
 }
-// the same layout `off` doubles further on (second buffer of the look-ahead: block k+1's panel factorisation writes its
-// T / S / partial products while block k's trailing update still reads its own)
-__host__ __device__ inline AuxLay shift_auxlay(AuxLay a, int64_t off) {
-  a.T += off; a.S += off; a.tau += off; a.piv += off; a.mx += off; a.bar += off; a.part += off; a.gram += off; a.w0 += off;
-  return a;
+__host__ __device__ inline int64_t auxlay_doubles(int nchunk, int ntile) {     // ONE copy (header + body)
+  return AUX_HDR + (int64_t)nchunk * 256 + (int64_t)nchunk * GSUB * 1024 + (int64_t)ntile * nchunk * 4096;
 }
-__host__ __device__ inline int64_t auxlay_doubles(int nchunk, int ntile) {
-  return 4 * 256 + 6 * 256 + 64 + 256 + 16 + 16 + (int64_t)nchunk * 256 + (int64_t)nchunk * GSUB * 1024 + (int64_t)ntile * nchunk * 4096;
+// the second copy of layout `a` (auxd = auxlay_doubles of the same nchunk, ntile)
+__host__ __device__ inline AuxLay second_auxlay(AuxLay a, int64_t auxd) {
+  const int64_t body = auxd - AUX_HDR;
+  a.T += AUX_HDR; a.S += AUX_HDR; a.tau += AUX_HDR; a.piv += AUX_HDR; a.mx += AUX_HDR; a.bar += AUX_HDR;
+  a.part += body; a.gram += body; a.w0 += body;
+  return a;
 }
 
 __device__ __forceinline__ double sel16(const double (&v)[16], int j) {

@@ -41,8 +41,56 @@ def _keep(svd_trunc, lam):
     raise TypeError(svd_trunc)
 
 
-def op_kron_compress_qr(wi, a, b, T, svd_trunc):
-    """Same inputs / outputs as ``oracle.mpbp.op_kron_compress`` (recursive_bp_factor.jl:118-131), device algorithm."""
+def _chol_shifted(G, shift):
+    """upper-triangular R with R^T R = G + s I, s = shift * trace-free scale of G; the shift grows tenfold until LAPACK's
+    ``potrf`` accepts the matrix (a rank-deficient Gram matrix has non-positive pivots at rounding level)."""
+    n = G.shape[0]
+    scale = float(np.abs(np.diag(G)).max())
+    if not scale > 0:
+        return np.zeros_like(G), 0.0
+    s = shift * scale
+    for _ in range(40):
+        try:
+            return np.linalg.cholesky(G + s * np.eye(n)).T, s
+        except np.linalg.LinAlgError:
+            s = max(s * 10.0, 1e-18 * scale)
+    raise np.linalg.LinAlgError("shifted Cholesky did not succeed")
+
+
+def gauge_factor(Y, gauge="householder"):
+    """R-only factor of ``Y`` (``R^T R = Y^T Y``) in the forms the round-4 experiment compares
+    (``tools/gram_gauge_experiment.py``, ``profiles/r04_gram_gauge_errors.txt``):
+
+    * ``householder`` - LAPACK ``geqrf`` (what the HIP engine's blocked Householder QR is checked against);
+    * ``gram`` - single pass: Cholesky of the Gram matrix ``Y^T Y`` (+ the smallest shift ``potrf`` accepts);
+    * ``cholqr2`` - shifted CholeskyQR2 (Fukaya, Kannan, Nakatsukasa, Yamamoto, Yanagisawa 2020): ``R1`` from the Gram
+      matrix with the shift ``11 (m n + n (n + 1)) u |Y|^2``, ``Q1 = Y R1^-1``, ``R2`` from the Gram matrix of ``Q1``,
+      ``R = R2 R1``;  ``cholqr3`` - one more pass on ``Q2 = Q1 R2^-1``.
+    """
+    if gauge == "householder":
+        return np.linalg.qr(Y, mode="r")
+    from scipy.linalg import solve_triangular
+    m, n = Y.shape
+    u = np.finfo(float).eps / 2
+    G = Y.T @ Y
+    if gauge == "gram":
+        return _chol_shifted(G, 0.0)[0]
+    R1, _ = _chol_shifted(G, 11.0 * (m * n + n * (n + 1)) * u)
+    if not R1.any():
+        return R1
+    R = R1
+    Q = solve_triangular(R1, Y.T, trans="T", lower=False).T               # Q1 = Y R1^-1
+    for _ in range({"cholqr2": 1, "cholqr3": 2}[gauge]):
+        Rk, _ = _chol_shifted(Q.T @ Q, 0.0)
+        R = Rk @ R
+        Q = solve_triangular(Rk, Q.T, trans="T", lower=False).T
+    return R
+
+
+def op_kron_compress_qr(wi, a, b, T, svd_trunc, gauge="householder"):
+    """Same inputs / outputs as ``oracle.mpbp.op_kron_compress`` (recursive_bp_factor.jl:118-131), device algorithm.
+    ``gauge`` selects how the triangular factor of sweep 1 is computed (``gauge_factor``); the device ships
+    ``householder``."""
     B1, d1 = a
     B2, d2 = b
     L = T + 1
@@ -78,7 +126,7 @@ def op_kron_compress_qr(wi, a, b, T, svd_trunc):
             Yx = (E.reshape(b_ * ny, bn * ny1) @ Zx).reshape(b_, ny, a_, r1)                  # [m2, y, m1, k]
             Y[:, :, xi] = np.transpose(Yx, (3, 1, 2, 0))
         Y = Y.reshape(r1 * ny * q, a_ * b_, order="F")
-        R = np.linalg.qr(Y, mode="r")
+        R = gauge_factor(Y, gauge)
         mx = np.abs(R).max()
         if mx > 0 and np.isfinite(mx):
             R = R / mx

@@ -157,6 +157,35 @@ def test_qr_batched_tree_many_nodes_two_per_cu_and_ragged_tail():
             assert np.abs(R[p] * sgn[:, None] - Rn).max() < 1e-11 * np.abs(Rn).max(), (r, c, p)
 
 
+def test_qr_batched_sequence_on_shared_scratch_caqr_then_lookahead():
+    """Consecutive time steps of a gauge sweep share one per-problem scratch.  A step taken by the communication-avoiding
+    form keeps its node slots in that scratch; a LATER step on the same scratch can fall to the look-ahead form (more rows:
+    the node slots no longer fit), whose cooperative panel kernel trusts arrival counters zeroed once per sweep.  The slots
+    used to run over the second scratch copy's counters (round-3 advisor); the two headers now sit in front of both bodies.
+    4128 x 320 -> tree (slots reach into the second copy), 8192 x 320 -> look-ahead, twice; every R against LAPACK."""
+    rng = np.random.default_rng(26)
+    rows, cols = [4128, 8192, 4128, 8192], 320
+    mats = [rng.standard_normal((r, cols)) * np.logspace(0, -8, cols)[None, :] for r in rows]
+    A = np.concatenate([np.asfortranarray(m).ravel(order="F") for m in mats])
+    R = np.zeros(sum(min(r, cols) * cols for r in rows))
+    path = np.zeros(len(rows), dtype=np.int32)
+    rws = np.array(rows, dtype=np.int32)
+    lib = mpbp_amd._lib.lib()
+    rc = lib.mpbp_selftest_qr_batched_seq(0, len(rows), rws.ctypes.data_as(C.POINTER(C.c_int32)), cols, _dp(A), _dp(R),
+                                          path.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 0, lib.mpbp_last_error(None)
+    assert list(path) == [1, 2, 1, 2], path          # the sequence really alternates between the two forms
+    off = 0
+    for s, m in enumerate(mats):
+        k = min(rows[s], cols)
+        Rs = R[off:off + k * cols].reshape((k, cols), order="F")
+        off += k * cols
+        Rn = np.linalg.qr(m, mode="r")
+        sgn = np.sign(np.diag(Rn)) * np.sign(np.diag(Rs))
+        sgn[sgn == 0] = 1
+        assert np.abs(Rs * sgn[:, None] - Rn).max() < 1e-11 * np.abs(Rn).max(), s
+
+
 def test_qr_batched_many_problems_fused_update():
     """Enough problems for the wave-per-tile-pair fused trailing update (k_trail4f) and the one-launch register panels
     with Gram + T (k_fpanel), the path a configs[1]-sized batch takes in the batched gauge sweep."""

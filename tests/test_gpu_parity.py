@@ -1089,13 +1089,13 @@ def test_generic_factor_loopy_binding_truncation_matches_oracle_gpu():
 
 def test_generic_factor_limits_are_reported_not_aborted():
     """The exhaustive update is exponential in the degree: a product bond beyond what one workgroup's panel holds is refused
-    with MPBP_EUNSUPPORTED at the sweep, and a generic factor on a chain periodic in time at construction."""
+    with MPBP_EUNSUPPORTED where the factor is set - at CONSTRUCTION of the host mirror, with the limit in the message
+    (round-3 advisor: it used to surface at the first sweep) - and so is a generic factor on a chain periodic in time."""
     A, lam, rho, alpha, phi, T = _sis_star_inputs()
     wg = [[M.GenericFactor(M.SISFactor(lam, rho, alpha)) for _ in range(T + 1)] for _ in range(4)]
-    bp = M.mpbp(M.IndexedBiDiGraph(A), wg, 2, T, phi=phi, max_bond=16)      # hub: 2 x 16^3 x 2 rows
     with pytest.raises(M.MPBPError) as ei:
-        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(16))
-    assert "generic factor" in str(ei.value)
+        M.mpbp(M.IndexedBiDiGraph(A), wg, 2, T, phi=phi, max_bond=16)      # hub: 2 x 16^3 x 2 rows
+    assert "generic factor" in str(ei.value) and "2048" in str(ei.value)
     with pytest.raises(M.MPBPError):
         M.periodic_mpbp(M.IndexedBiDiGraph(A), wg, 2, T, phi=phi, max_bond=4)
 

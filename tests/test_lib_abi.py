@@ -52,3 +52,23 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     want = [C.sizeof(L.Desc), C.sizeof(L.Trunc), C.sizeof(L.Stats), C.sizeof(L.Layout), L.Desc.periodic.offset,
             L.Desc.stream.offset, L.Stats.jacobi_calls.offset]
     assert got == want
+
+
+def test_every_included_header_is_in_the_staleness_check():
+    """Round-3 review item 6: `build()` recompiles an object when a header is newer - so every `#include "..."` reachable
+    from the two translation units must be in `_lib.headers()` (csrc/cq_kernels.h was not, in round 3)."""
+    L = mpbp_amd._lib
+    known = {os.path.realpath(h) for h in L.headers()}
+    assert all(os.path.exists(h) for h in known)
+    seen, todo = set(), [os.path.join(L.CSRC, s) for s in L.SOURCES]
+    while todo:
+        f = todo.pop()
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f).read(), flags=re.M):
+            cands = [os.path.join(os.path.dirname(f), inc), os.path.join(L.CSRC, inc), os.path.join(ROOT, "include", inc)]
+            hit = [os.path.realpath(c) for c in cands if os.path.exists(c)]
+            assert hit, f'{f} includes "{inc}", which is not in the tree'
+            if hit[0] not in seen:
+                seen.add(hit[0])
+                todo.append(hit[0])
+    assert seen, "no includes parsed"
+    assert seen <= known, f"headers missing from the staleness check: {sorted(seen - known)}"
