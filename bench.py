@@ -367,7 +367,7 @@ def main():
     bp._L.mpbp_set_profiling(bp._h, 2 if args.phase_profile else 1)
     owned = np.arange(lo, hi, dtype=np.int32)
     trunc = M.TruncBond(Mb)
-    ms_orth, n_orth, ms_dev = [], [], []
+    ms_orth, n_orth, ms_dev, ms_xchg = [], [], [], []
 
     def step(record):
         M.onebpiter(bp, owned, trunc)
@@ -375,8 +375,13 @@ def main():
             st = bp.last_stats
             ms_orth.append(st.ms_orth); n_orth.append(st.n_orth_launches); ms_dev.append(st.ms_total)
         if exchange:
+            # mpbp_sweep returned after a stream synchronise: everything from here to the next synchronise is the exchange
+            # (including the wait for the slowest rank: the collective cannot complete before every rank has entered it)
+            t_x = time.perf_counter()
             D.allgather_slots(cores_t, bonds_t, S, rank, world)
             torch.cuda.synchronize()
+            if record:
+                ms_xchg.append((time.perf_counter() - t_x) * 1e3)
 
     def fence():
         if world > 1:
@@ -422,6 +427,14 @@ def main():
         print("engine phase profile (workgroup-seconds, cavity-op launches):", file=sys.stderr)
         for n_, v in zip(names, ph):
             print(f"  {n_:10s} {v:10.3f} s  {100 * v / max(tot, 1e-30):5.1f} %", file=sys.stderr)
+    # per-rank split of a step, so that the first multi-GPU record can be read: the sweep of the rank's own node block
+    # (device time of mpbp_sweep) and the exchange (all-gather + the wait for the slowest rank), means over the timed steps
+    per_rank = None
+    if world > 1:
+        mine = (float(np.mean(ms_dev)) if ms_dev else 0.0, float(np.mean(ms_xchg)) if ms_xchg else 0.0)
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        per_rank = {"sweep_ms": [a for a, _ in allr], "exchange_ms": [b for _, b in allr]}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         replicas = world > 1 and not shardable       # configs 3 / 4 do not shard by node: N independent replicas
@@ -446,7 +459,7 @@ def main():
         # cannot run the profiler on itself) - quoted, not measured in this run, and only for the configuration they
         # were taken on
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_eng_kernel.json")
             if world == 1 and args.config == 1 and (N, T, Mb) == (1024, 50, 20) and os.path.exists(pmc):
                 with open(pmc) as fh:
@@ -487,6 +500,8 @@ def main():
                "config": {"workload": wl, "edges": int(E), "edge_updates_per_step": int(e_job), "parallelism": par,
                           "bond_profile_max": prof[:5] + ["..."] + prof[-4:]},
                "device_ms_per_step": float(np.mean(ms_dev)), "device_ms_steps": [float(v) for v in ms_dev], "roofline": roofline}
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         free_b, tot_b = torch.cuda.mem_get_info(dev)
         out["hbm_in_use_GiB"] = (tot_b - free_b) / 2 ** 30
         if world == 1 and not args.no_cpu_baseline and args.config == 1:

@@ -240,6 +240,10 @@ int mpbp_selftest_svd(int32_t device, int32_t rows, int32_t cols, const double* 
  * column norms after convergence and the number of sweeps (-1: not converged) */
 int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps,
                               int32_t* sweeps);
+/* the same through the two-level (block) Jacobi: column blocks, block pairs LDS resident, one launch per round of the
+ * block tournament - the form the truncating sweep takes for factors of ~100 columns and more */
+int mpbp_selftest_jacobi_block(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps,
+                               int32_t* sweeps);
 /* nprob independent rows x cols matrices (A: [nprob][rows x cols] column-major) through the grid-level batched QR of
  * the gauge sweep (csrc/v2_kernels.h); R: [nprob][min(rows,cols) x cols]; force_tall: column-step panels always. */
 int mpbp_selftest_qr_batched(int32_t device, int32_t rows, int32_t cols, int32_t nprob, int32_t force_tall,

@@ -56,7 +56,7 @@ EXPORTS = ["mpbp_create", "mpbp_destroy", "mpbp_last_error", "mpbp_slab_layout",
            "mpbp_set_factor", "mpbp_set_generic_factor", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
            "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_get_belief_train", "mpbp_pair_beliefs",
            "mpbp_free_energy", "mpbp_logz", "mpbp_allgather_slots", "mpbp_twovar_marginals", "mpbp_set_profiling", "mpbp_phase_profile", "mpbp_selftest_gemm", "mpbp_selftest_qr", "mpbp_selftest_qr_bench",
-           "mpbp_selftest_jacobi_bench", "mpbp_selftest_svd", "mpbp_selftest_qr_batched", "mpbp_selftest_qr_batched_seq", "mpbp_selftest_jacobi_grid"]
+           "mpbp_selftest_jacobi_bench", "mpbp_selftest_svd", "mpbp_selftest_qr_batched", "mpbp_selftest_qr_batched_seq", "mpbp_selftest_jacobi_grid", "mpbp_selftest_jacobi_block"]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -138,6 +138,7 @@ def lib():
     L.mpbp_selftest_qr_bench.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp]
     L.mpbp_selftest_svd.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
     L.mpbp_selftest_jacobi_grid.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, C.c_int32, ip]
+    L.mpbp_selftest_jacobi_block.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, C.c_int32, ip]
     L.mpbp_selftest_qr_batched.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
     L.mpbp_selftest_qr_batched_seq.argtypes = [C.c_int32, C.c_int32, ip, C.c_int32, dp, dp, ip]
     _lib = L

@@ -141,18 +141,6 @@ __device__ __forceinline__ double reduce_rows(double s) {
   return s;
 }
 
-template <int PJ, bool TREE, int CJ>
-__device__ __forceinline__ void bcast_col(const double (&P)[4][4][4], double (&x)[4][4]) {
-#pragma unroll
-  for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-#if defined(CQ_VAR) && CQ_VAR == 4
-    for (int e = 0; e < 4; e++) x[rb][e] = (TREE && rb > PJ) ? 0.0 : P[rb][e][PJ];
-#else
-    for (int e = 0; e < 4; e++) x[rb][e] = (TREE && rb > PJ) ? 0.0 : bcast16<CJ>(P[rb][e][PJ]);
-#endif
-}
-
 #ifdef CQ_PROF
 __device__ unsigned long long cq_prof[4][8];
 #define CQ_T(slot) do { const unsigned long long t1_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) cq_prof[w][slot] += t1_ - t0_; t0_ = t1_; } while (0)
@@ -163,78 +151,69 @@ __device__ unsigned long long cq_prof[4][8];
 // The sixteen column steps of sub-panel PJ.  During the steps column cj keeps the UNSCALED vector x below its pivot (the
 // update of the other columns is P -= x (scale tw)); the columns are scaled to v = x scale once, after the last step.
 // MASK: some of this wave's rows are excluded (the first segment's rows up to the pivot; the zero rows of a triangle).
-template <int PJ, bool TREE, bool MASK>
-__device__ __forceinline__ void subpanel_steps_w(double (&P)[4][4][4], double (&mytau)[4], int w, ldbl* lds) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  ldbl* part = lds + L2_PART;
-  ldbl* rowb = lds + L2_ROW;
-  double myscale = 0.0;
+// The steps are written out with the column index CJ a compile-time constant (round-3 review item 2: as a run-time loop
+// the sixteen broadcasts sat behind a 16-way `switch` - an indirect jump per step that the instruction prefetch cannot
+// follow - and every pivot-row access was a select): the broadcast, the readlane of the pivot column and the pivot-row
+// element are immediates, and the row groups a step cannot touch (above the pivot's group in the first segment of a dense
+// node) are skipped at compile time.
+template <int PJ, bool TREE, bool MASK, int CJ>
+__device__ __forceinline__ void col_step(double (&P)[4][4][4], double (&mytau)[4], double& myscale, int w, int g, int c, ldbl* part, ldbl* rowb) {
+  constexpr int par = CJ & 1, GJ = CJ >> 2, EJ = CJ & 3;
+  // row groups of this wave that reflector CJ can touch
+  auto live = [](int rb) constexpr { return TREE ? (rb <= PJ) : (MASK ? (rb >= PJ) : true); };
 #ifdef CQ_PROF
   unsigned long long t0_ = __builtin_readcyclecounter();
 #endif
-  for (int cj = 0; cj < 16; cj++) {
-    const int par = cj & 1;
-    double x[4][4];
-    switch (cj) {
-      case 0: bcast_col<PJ, TREE, 0>(P, x); break;   case 1: bcast_col<PJ, TREE, 1>(P, x); break;
-      case 2: bcast_col<PJ, TREE, 2>(P, x); break;   case 3: bcast_col<PJ, TREE, 3>(P, x); break;
-      case 4: bcast_col<PJ, TREE, 4>(P, x); break;   case 5: bcast_col<PJ, TREE, 5>(P, x); break;
-      case 6: bcast_col<PJ, TREE, 6>(P, x); break;   case 7: bcast_col<PJ, TREE, 7>(P, x); break;
-      case 8: bcast_col<PJ, TREE, 8>(P, x); break;   case 9: bcast_col<PJ, TREE, 9>(P, x); break;
-      case 10: bcast_col<PJ, TREE, 10>(P, x); break; case 11: bcast_col<PJ, TREE, 11>(P, x); break;
-      case 12: bcast_col<PJ, TREE, 12>(P, x); break; case 13: bcast_col<PJ, TREE, 13>(P, x); break;
-      case 14: bcast_col<PJ, TREE, 14>(P, x); break; default: bcast_col<PJ, TREE, 15>(P, x); break;
-    }
-    CQ_T(0);
-    double s0 = 0.0, s1 = 0.0;
+  double x[4][4];
+  double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int rb = 0; rb < 4; rb++) {
-      if (TREE && rb > PJ) continue;
+  for (int rb = 0; rb < 4; rb++) {
+    if (!live(rb)) continue;
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (MASK) {
-          bool incl;
-          if (TREE) incl = (rb < PJ || 4 * g + e <= cj);                              // segments 1..3 of a stack of triangles
-          else incl = (rb > PJ) || (rb == PJ && 4 * g + e > cj);                      // first segment of a dense node
-          x[rb][e] = incl ? x[rb][e] : 0.0;
-        }
-        if (e & 1) s1 += x[rb][e] * P[rb][e][PJ]; else s0 += x[rb][e] * P[rb][e][PJ];
+    for (int e = 0; e < 4; e++) {
+      double xv = bcast16<CJ>(P[rb][e][PJ]);
+      if (MASK) {
+        bool incl;
+        if (TREE) incl = (rb < PJ || 4 * g + e <= CJ);                              // segments 1..3 of a stack of triangles
+        else incl = (rb > PJ) || (4 * g + e > CJ);                                  // first segment of a dense node (rb == PJ)
+        xv = incl ? xv : 0.0;
       }
+      x[rb][e] = xv;
+      if (e & 1) s1 += xv * P[rb][e][PJ]; else s0 += xv * P[rb][e][PJ];
     }
-    const double sw = reduce_rows(s0 + s1);
-    if (g == 0) part[par * 64 + w * 16 + c] = sw;
-    if (w == 0 && g == (cj >> 2)) {
-      const int ee = cj & 3;
-      rowb[par * 16 + c] = (ee == 0) ? P[PJ][0][PJ] : (ee == 1) ? P[PJ][1][PJ] : (ee == 2) ? P[PJ][2][PJ] : P[PJ][3][PJ];
-    }
-    CQ_T(1);
-    lds_barrier();
-    CQ_T(2);
-    const double dt = (part[par * 64 + c] + part[par * 64 + 16 + c]) + (part[par * 64 + 32 + c] + part[par * 64 + 48 + c]);
-    const double rv = rowb[par * 16 + c];
-    const double ss = readlane_d(dt, cj), alpha = readlane_d(rv, cj);
-    CQ_T(3);
-    const Refl h = dlarfg(alpha, ss);
-    const bool iscj = (c == cj);
-    mytau[PJ] = iscj ? h.tau : mytau[PJ];
-    myscale = iscj ? h.scale : myscale;
-    const double tw = (c <= cj) ? 0.0 : h.tau * (rv + h.scale * dt);
-    const double tws = -h.scale * tw;
-    CQ_T(4);
-#pragma unroll
-    for (int rb = 0; rb < 4; rb++) {
-      if (TREE && rb > PJ) continue;
-#pragma unroll
-      for (int e = 0; e < 4; e++) P[rb][e][PJ] += x[rb][e] * tws;
-    }
-    if (w == 0 && g == (cj >> 2)) {
-      const int ee = cj & 3;
-      const double nv = iscj ? h.beta : (rv - tw);
-#pragma unroll
-      for (int e = 0; e < 4; e++) P[PJ][e][PJ] = (e == ee) ? nv : P[PJ][e][PJ];
-    }
-    CQ_T(5);
   }
+  CQ_T(1);
+  const double sw = reduce_rows(s0 + s1);
+  if (g == 0) part[par * 64 + w * 16 + c] = sw;
+  if (w == 0 && g == GJ) rowb[par * 16 + c] = P[PJ][EJ][PJ];
+  lds_barrier();
+  CQ_T(2);
+  const double dt = (part[par * 64 + c] + part[par * 64 + 16 + c]) + (part[par * 64 + 32 + c] + part[par * 64 + 48 + c]);
+  const double rv = rowb[par * 16 + c];
+  const double ss = readlane_d(dt, CJ), alpha = readlane_d(rv, CJ);
+  CQ_T(3);
+  const Refl h = dlarfg(alpha, ss);
+  const bool iscj = (c == CJ);
+  mytau[PJ] = iscj ? h.tau : mytau[PJ];
+  myscale = iscj ? h.scale : myscale;
+  const double tw = (c <= CJ) ? 0.0 : h.tau * (rv + h.scale * dt);
+  const double tws = -h.scale * tw;
+  CQ_T(4);
+#pragma unroll
+  for (int rb = 0; rb < 4; rb++) {
+    if (!live(rb)) continue;
+#pragma unroll
+    for (int e = 0; e < 4; e++) P[rb][e][PJ] += x[rb][e] * tws;
+  }
+  if (w == 0 && g == GJ) P[PJ][EJ][PJ] = iscj ? h.beta : (rv - tw);
+  CQ_T(5);
+  if constexpr (CJ + 1 < 16) col_step<PJ, TREE, MASK, CJ + 1>(P, mytau, myscale, w, g, c, part, rowb);
+}
+template <int PJ, bool TREE, bool MASK>
+__device__ __forceinline__ void subpanel_steps_w(double (&P)[4][4][4], double (&mytau)[4], int w, ldbl* lds) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  double myscale = 0.0;
+  col_step<PJ, TREE, MASK, 0>(P, mytau, myscale, w, g, c, lds + L2_PART, lds + L2_ROW);
   // v = x scale below the pivots
 #pragma unroll
   for (int rb = 0; rb < 4; rb++) {
@@ -249,33 +228,26 @@ __device__ __forceinline__ void subpanel_steps_w(double (&P)[4][4][4], double (&
 }
 
 // A wave of the first segment of a stack of triangles has no rows below the pivots: it only hands out the pivot rows.
+template <int PJ, int CJ>
+__device__ __forceinline__ void pivot_step(double (&P)[4][4][4], double (&mytau)[4], int g, int c, ldbl* part, ldbl* rowb) {
+  constexpr int par = CJ & 1, GJ = CJ >> 2, EJ = CJ & 3;
+  if (g == 0) part[par * 64 + c] = 0.0;
+  if (g == GJ) rowb[par * 16 + c] = P[PJ][EJ][PJ];
+  lds_barrier();
+  const double dt = (part[par * 64 + c] + part[par * 64 + 16 + c]) + (part[par * 64 + 32 + c] + part[par * 64 + 48 + c]);
+  const double rv = rowb[par * 16 + c];
+  const double ss = readlane_d(dt, CJ), alpha = readlane_d(rv, CJ);
+  const Refl h = dlarfg(alpha, ss);
+  const bool iscj = (c == CJ);
+  mytau[PJ] = iscj ? h.tau : mytau[PJ];
+  const double tw = (c <= CJ) ? 0.0 : h.tau * (rv + h.scale * dt);
+  if (g == GJ) P[PJ][EJ][PJ] = iscj ? h.beta : (rv - tw);
+  if constexpr (CJ + 1 < 16) pivot_step<PJ, CJ + 1>(P, mytau, g, c, part, rowb);
+}
 template <int PJ>
 __device__ __forceinline__ void subpanel_steps_pivots(double (&P)[4][4][4], double (&mytau)[4], ldbl* lds) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  ldbl* part = lds + L2_PART;
-  ldbl* rowb = lds + L2_ROW;
-  for (int cj = 0; cj < 16; cj++) {
-    const int par = cj & 1;
-    if (g == 0) part[par * 64 + c] = 0.0;
-    if (g == (cj >> 2)) {
-      const int ee = cj & 3;
-      rowb[par * 16 + c] = (ee == 0) ? P[PJ][0][PJ] : (ee == 1) ? P[PJ][1][PJ] : (ee == 2) ? P[PJ][2][PJ] : P[PJ][3][PJ];
-    }
-    lds_barrier();
-    const double dt = (part[par * 64 + c] + part[par * 64 + 16 + c]) + (part[par * 64 + 32 + c] + part[par * 64 + 48 + c]);
-    const double rv = rowb[par * 16 + c];
-    const double ss = readlane_d(dt, cj), alpha = readlane_d(rv, cj);
-    const Refl h = dlarfg(alpha, ss);
-    const bool iscj = (c == cj);
-    mytau[PJ] = iscj ? h.tau : mytau[PJ];
-    const double tw = (c <= cj) ? 0.0 : h.tau * (rv + h.scale * dt);
-    if (g == (cj >> 2)) {
-      const int ee = cj & 3;
-      const double nv = iscj ? h.beta : (rv - tw);
-#pragma unroll
-      for (int e = 0; e < 4; e++) P[PJ][e][PJ] = (e == ee) ? nv : P[PJ][e][PJ];
-    }
-  }
+  pivot_step<PJ, 0>(P, mytau, g, c, lds + L2_PART, lds + L2_ROW);
 }
 
 template <int PJ, bool TREE>
@@ -474,9 +446,6 @@ __device__ __forceinline__ void cross_grams(const double (&P)[4][4][4], int w, i
   }
 }
 
-template <bool TREE>
-__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS,
-                                            int col_next, unsigned touch_off);
 
 // k_cq_fac2: grid (nodes of the level, problems), 256 threads, FAC_LDS_DOUBLES doubles of dynamic LDS (two workgroups per CU).
 template <bool TREE>
@@ -611,7 +580,7 @@ __device__ __forceinline__ void load_tile(const gdbl* Y, long ld, const int (&ba
 // register allocator does can be hit by the late write) and are issued AFTER the wave has waited for its own tile, from
 // inline assembly the compiler's wait-count model does not see: no instruction waits for them, a later wait at most over-waits.
 __device__ __forceinline__ void touch_tile(const gdbl* Y, long ld, const int (&base)[4], int nrb, int col_next, unsigned lds_off) {
-#ifndef CQ_NO_TOUCH
+#if !defined(CQ_NO_TOUCH) && !defined(CQ_NO_GLOBAL)
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const gdbl* cp = Y + (long)(col_next + c) * ld;
 #pragma unroll
@@ -625,18 +594,20 @@ __device__ __forceinline__ void touch_tile(const gdbl* Y, long ld, const int (&b
   }
 #endif
 }
-template <bool TREE>
-__device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS,
-                                             int col_next, unsigned touch_off);
-template <bool TREE>
-__device__ __forceinline__ void update_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, const ldbl* V, const ldbl* OPS,
-                                            int col_next, unsigned touch_off) {
-  d4 C[16];
-  load_tile(Y, ld, base, nrb, col0, C);
-  compute_tile<TREE>(Y, ld, base, nrb, col0, C, V, OPS, col_next, touch_off);
-}
+#ifdef CQ_UPROF
+__device__ unsigned long long cq_uprof[8];
+#define CQ_UT(slot) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&cq_uprof[slot], t1_ - cq_ut0); cq_ut0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CQ_UT_DECL unsigned long long cq_ut0 = __builtin_readcyclecounter()
+#else
+#define CQ_UT(slot) do {} while (0)
+#define CQ_UT_DECL do {} while (0)
+#endif
 // the tile in C (load_tile) against the node's image; the updated tile is stored
-template <bool TREE>
+// NEXT: the wave has another tile (at column col_next) after this one: it is touched (touch_tile) once this one is in registers.
+// (Tried in round 4 and measured no faster: the next tile's row groups requested in phase C, each right behind the store
+// that frees its registers - with the touches the tile load is not what a wave waits for; without them the last row
+// groups arrive late: 117 against 108 us for 64 tiles x 64 nodes, tools/probes/cq_upd_probe.hip.)
+template <bool TREE, bool NEXT>
 __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS,
                                              int col_next, unsigned touch_off) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
@@ -658,6 +629,11 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
       cE[s] = lo + hi; cO[s] = lo - hi;
     }
   }
+  CQ_UT_DECL;
+#ifdef CQ_UPROF
+  { double sink = 0; for (int rb = 0; rb < 16; rb++) sink += C[rb][0] + C[rb][3]; if (sink == 1.2345e301) cp[0] = sink; }   // wait for the tile here
+  CQ_UT(1);
+#endif
   // ------------------------------------------------ phase A: W0_p = V_p^T C
   // The LDS operands are fetched one row group ahead by hand and the schedule is pinned per group: left alone, the
   // scheduler hoists dozens of ds_reads above the MFMA chain and spills the C tile.
@@ -689,11 +665,12 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
       __builtin_amdgcn_sched_barrier(0);
     }
     w[p] = acc;
-    if (p == 0 && col_next >= 0) {              // the tile is in registers by now (the first MFMAs waited for it)
+    if (NEXT && p == 0) {                       // the tile is in registers by now (the first MFMAs waited for it)
       touch_tile(Y, ld, base, nrb, col_next, touch_off);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  CQ_UT(2);
   // ------------------------------------------------ phase B: W_p = T_p^T (W0_p - sum_{r<p} S_pr W_r)
 #pragma unroll
   for (int p = 0; p < 4; p++) {
@@ -712,19 +689,22 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
   }
 #pragma unroll
   for (int p = 0; p < 4; p++) w[p] = -w[p];
+  CQ_UT(3);
   // ------------------------------------------------ phase C: C -= sum_p V_p W_p
   // (the LDS operands of row group rb + 1 are fetched while the MFMAs of row group rb run, as in phase A: fetched right in
   //  front of their MFMAs, every (row group, sub-panel) waited ~100 cycles for its four reads)
   double a[4][4], an[4][4];
+  // all sixteen base pointers up front (the image is 128 KB, a ds_read immediate reaches 64 KB: even / odd sub-panel x
+  // lower / upper half) - computed inside the loop they were 256 address adds per tile between the MFMAs
+  const ldbl* cb[2][2][4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) { cb[0][0][s] = V + cE[s]; cb[0][1][s] = V + cE[s] + 8192; cb[1][0][s] = V + cO[s]; cb[1][1][s] = V + cO[s] + 8192; }
   auto fetch = [&](int rb, double (&dst)[4][4]) {
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       if (tree_skip(TREE, rb, p)) continue;
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const ldbl* vb = V + ((p & 1) ? cO[s] : cE[s]) + ((rb < 8) ? 0 : 8192);
-        dst[p][s] = vb[16 * p + 1024 * (rb & 7)];
-      }
+      for (int s = 0; s < 4; s++) dst[p][s] = cb[p & 1][rb >> 3][s][16 * p + 1024 * (rb & 7)];
     }
   };
   fetch(0, a);
@@ -738,20 +718,32 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
 #pragma unroll
       for (int s = 0; s < 4; s++) acc = mfma(a[p][s], w[p][s], acc);
     }
+#ifdef CQ_NO_GLOBAL            // probe builds: the tile never leaves the registers (compute-only ceiling of the wave's instruction stream)
+    C[rb] = acc;
+    if (acc[0] == 1.2345e301 && rb < nrb) __builtin_nontemporal_store(acc, reinterpret_cast<gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
+#else
     if (rb < nrb) __builtin_nontemporal_store(acc, reinterpret_cast<gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
+#endif
 #pragma unroll
     for (int p = 0; p < 4; p++)
 #pragma unroll
       for (int s = 0; s < 4; s++) a[p][s] = an[p][s];
     __builtin_amdgcn_sched_barrier(0);
   }
+  CQ_UT(4);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_cq_upd: grid (tile groups, nodes of the level, problems), 512 or 256 threads, IMG_DOUBLES doubles of dynamic LDS.
 // Tiles [tfirst + tg * tpg, + tpg) of the columns right of the block, one per wave at a time.
 // (Tried: four-wave workgroups that fetch the next tile while the current one is updated, two tile buffers in the 512
-// registers of a lone wave - the allocator spills 57-206 registers around the two buffers and the kernel is 8 % slower.)
+// registers of a lone wave - the allocator spills 57-206 registers around the two buffers and the kernel is 8 % slower.
+// Round 4, tools/probes/cq_upd_probe.hip, 128 tiles x 64 nodes, all on one box: (i) TWO tiles per wave against the same LDS
+// operands - every ds_read feeds two MFMAs, 256 + 256 registers, no spill - 37-38 against 38-40 TFLOP/s: the LDS operand
+// stream is not what a wave waits for; (ii) the 256 LDS address adds of phase C hoisted (kept): no change - nor is VALU
+// issue; (iii) no global traffic at all (-DCQ_NO_GLOBAL): 44 TFLOP/s = 23 us per tile and wave against 14.7 us of MFMA issue
+// at 2.4 GHz, 20.8 us with half the CUs busy - the stream runs at ~77 % of MFMA issue in CYCLES and the rest is the clock
+// the part sustains under fp64 MFMA load; (iv) eight-wave workgroups (two waves per SIMD, 256 registers, spills): 30-33.)
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int level, int slot, int node, int tg, int tpg,
@@ -767,21 +759,44 @@ __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, i
   const int nrb = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) >> 4;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int nwave = NT >> 6;
+#ifdef CQ_UPROF
+  const unsigned long long cq_wg_t0 = __builtin_readcyclecounter();
+#endif
+  // The node's image (148 KB) -> LDS by LDS-DMA: 148 wave-instructions of 1 KiB (global_load_lds_dwordx4, no register
+  // staging), all in flight at once, and the wave's FIRST tile is requested behind them before anybody waits.  (As a plain
+  // copy loop the compiler serialised it - two 16-byte loads, wait, two LDS writes, 18 round trips per thread: ~12 us per
+  // workgroup, as long as two tiles, during which the matrix pipes idle.)
   {
-    const gd4* srcv = reinterpret_cast<const gd4*>((const gdbl*)Pr.aux + ws_off + (long)slot * IMG_DOUBLES);
-    typedef __attribute__((address_space(3))) d4 ld4;
-    ld4* dstv = reinterpret_cast<ld4*>(lds);
-    for (int i = tid; i < IMG_DOUBLES / 4; i += NT) dstv[i] = srcv[i];
+    const gdbl* src = (const gdbl*)Pr.aux + ws_off + (long)slot * IMG_DOUBLES;
+    const int lane = tid & 63;
+    static_assert(IMG_DOUBLES % 128 == 0, "the image is a whole number of 1 KiB pieces");
+    for (int ch = wave; ch < IMG_DOUBLES / 128; ch += nwave)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ch * 128 + lane * 2),
+                                       (__attribute__((address_space(3))) void*)(lds + ch * 128), 16, 0, 0);
   }
-  __syncthreads();
   const int t1 = min(t0 + tpg, ntl);
   gdbl* Y = (gdbl*)Pr.Y;
+  d4 C[16];
+  int t = t0 + wave;
+  if (t < t1) load_tile(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C);
+  __syncthreads();
+#ifdef CQ_UPROF
+  if ((tid & 63) == 0) { atomicAdd(&cq_uprof[0], __builtin_readcyclecounter() - cq_wg_t0); atomicAdd(&cq_uprof[6], 1ull); }
+#endif
   if (level == 0) {
-    for (int t = t0 + wave; t < t1; t += nwave)
-      update_tile<false>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V, (t + nwave < t1) ? jb + 64 + 16 * (t + nwave) : -1, touch_off);
+    for (bool first = true; t < t1; t += nwave, first = false) {
+#ifndef CQ_NO_GLOBAL
+      if (!first) load_tile(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C);
+#endif
+      if (t + nwave < t1) compute_tile<false, true>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C, lds, lds + IMG_V, jb + 64 + 16 * (t + nwave), touch_off);
+      else compute_tile<false, false>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C, lds, lds + IMG_V, 0, touch_off);
+    }
   } else {
-    for (int t = t0 + wave; t < t1; t += nwave)
-      update_tile<true>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, lds, lds + IMG_V, (t + nwave < t1) ? jb + 64 + 16 * (t + nwave) : -1, touch_off);
+    for (bool first = true; t < t1; t += nwave, first = false) {
+      if (!first) load_tile(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C);
+      if (t + nwave < t1) compute_tile<true, true>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C, lds, lds + IMG_V, jb + 64 + 16 * (t + nwave), touch_off);
+      else compute_tile<true, false>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C, lds, lds + IMG_V, 0, touch_off);
+    }
   }
 }
 

@@ -22,6 +22,18 @@ inline int r32i(int x) { return (x + 31) & ~31; }
 
 struct QrDims { int rows, cols, kmax; };
 
+// columns per block of the two-level Jacobi for factors of m rows, n columns: a block pair (2 nb columns, odd leading
+// dimension) fits 150 KB of LDS, about eight blocks per factor (four workgroups per problem, seven launches per sweep), at
+// most 32 columns (an inner sweep is 2 nb - 1 rounds with a barrier each); 0: does not fit (m > 1200)
+inline int jac_block_nb(int m, int n) {
+  static const int forced = [] { const char* e = getenv("MPBP_JACOBI_NB"); return e ? atoi(e) : 0; }();
+  const int fit = (int)((150 * 1024 / 8 - 32) / (2 * (int64_t)(m | 1)));
+  if (fit < 4) return 0;
+  int nb = forced > 0 ? forced : std::max(8, (n + 7) / 8);
+  nb = std::min(std::min(nb, 32), fit);
+  return std::max(nb, 2);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Look-ahead for the latency-bound case (one or two LARGE problems per launch: configs[3] hubs, configs[4]): the panel
 // factorisation of block k+1 (17 cooperative column steps + Gram + T per 16 columns, ~25 launches per 64 columns, a
@@ -97,6 +109,7 @@ static void set_func_attrs_once() {
   hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
   hipFuncSetAttribute((const void*)cq::k_cq_fac2x2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
   hipFuncSetAttribute((const void*)cq::k_cq_updfac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
+  hipFuncSetAttribute((const void*)v2::k_jac_block, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 }
 
 // Launch sequence of one R-only QR over a batch whose dimensions `dims` are known on the host.
@@ -208,16 +221,20 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       // tiles per workgroup: one tile per wave and four-wave workgroups for the small upper levels; else the number of tile
       // groups with the fewest (rounds over the CUs) x (time of a workgroup: ~12 us of image load + 6.2 us per tile, measured
       // with the chip full) - it decides how the last round is filled
+      static const double img_us = [] { const char* e = getenv("MPBP_CQ_IMG_US"); return e ? atof(e) : 12.0; }();
+      static const int upd_nt = [] { const char* e = getenv("MPBP_CQ_NT"); return (e && atoi(e) == 512) ? 512 : 256; }();
       auto tile_groups = [&](int ntl, int n, int& tpg, int& nthr) {
         const int64_t tiles = (int64_t)ntl * n * P;
-        tpg = 8; nthr = 512;
+        // four-wave workgroups always: the eight-wave build (two waves per SIMD at 256 registers) spills and measured
+        // 30-33 against 38-40 TFLOP/s on every tile-group size (tools/probes/cq_upd_probe.hip); it only remains for MPBP_CQ_NT=512
+        tpg = 8; nthr = upd_nt;
         if (tiles <= 4 * ncu) { tpg = 4; nthr = 256; return; }
         double best = 1e30;
         for (int g = 1; g <= (ntl + 7) / 8; g++) {
           const int t = (ntl + g - 1) / g;
           if (t > 64) continue;
           const int64_t wgs = (int64_t)((ntl + t - 1) / t) * n * P;
-          const double cost = (double)((wgs + ncu - 1) / ncu) * (12.0 + 6.2 * t);
+          const double cost = (double)((wgs + ncu - 1) / ncu) * (img_us + 6.2 * t);
           if (cost < best) { best = cost; tpg = t; }
         }
       };
@@ -460,7 +477,7 @@ extern "C" int mpbp_selftest_qr_batched_seq(int32_t device, int32_t nshape, cons
 
 // self test of the multi-launch Jacobi (k_jac_round / k_jac_check): A [m x n] (ld m|1 inside) -> column norms after
 // convergence (= singular values, unsorted) and the number of sweeps (-1: not converged within maxsweeps)
-extern "C" int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps, int32_t* sweeps) {
+static int jacobi_selftest(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps, int32_t* sweeps, bool block) {
   ST2CHK(hipSetDevice(device));
   if (m < 1 || n < 1 || n > m || m > 1024) { g_create_error = "need 1 <= n <= m <= 1024"; return MPBP_EINVAL; }
   const int ldJ = v2::jac_ld(m);
@@ -472,21 +489,46 @@ extern "C" int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, c
   ST2CHK(hipMemcpy(dJA, JA.data(), sizeof(double) * JA.size(), hipMemcpyHostToDevice));
   double hs[8] = {0, 0, 0, fro2, 0, 0, (n < 2) ? 1.0 : 0.0, 0};
   ST2CHK(hipMemcpy(dscal, hs, sizeof hs, hipMemcpyHostToDevice));
+  hs[7] = (double)n;
+  ST2CHK(hipMemcpy(dscal, hs, sizeof hs, hipMemcpyHostToDevice));
+  int32_t* dact = nullptr;
+  ST2CHK(hipMalloc(&dact, sizeof(int32_t) * n));
+  { std::vector<int32_t> ha(n); for (int i = 0; i < n; i++) ha[i] = i; ST2CHK(hipMemcpy(dact, ha.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice)); }
   v2::SvdDesc D{};
-  D.JA = dJA; D.Rr = m; D.r1 = n; D.scal = dscal;
+  D.JA = dJA; D.Rr = m; D.r1 = n; D.scal = dscal; D.act = dact;
   ST2CHK(hipMemcpy(dd, &D, sizeof D, hipMemcpyHostToDevice));
-  const int ne = (n + 1) & ~1;
-  for (int sw = 0; sw < maxsweeps; sw++) {
-    for (int r = 0; r < ne - 1; r++) hipLaunchKernelGGL(v2::k_jac_round, dim3((ne / 2 + 15) / 16, 1), dim3(512), 0, 0, (const v2::SvdDesc*)dd, r);
-    hipLaunchKernelGGL(v2::k_jac_check, dim3(1), dim3(64), 0, 0, (const v2::SvdDesc*)dd, 1);
+  if (block) {
+    set_func_attrs_once();
+    const int nb = jac_block_nb(m, n);
+    if (nb < 2) { g_create_error = "factor too tall for an LDS-resident block pair"; return MPBP_EUNSUPPORTED; }
+    const int nblk = (n + nb - 1) / nb, ne = (nblk + 1) & ~1;
+    const size_t jlds = sizeof(double) * ((size_t)(m | 1) * 2 * nb + 32);
+    for (int sw = 0; sw < maxsweeps; sw++) {
+      for (int r = 0; r < std::max(1, ne - 1); r++) hipLaunchKernelGGL(v2::k_jac_block, dim3(ne / 2, 1), dim3(512), jlds, 0, (const v2::SvdDesc*)dd, r, nb);
+      hipLaunchKernelGGL(v2::k_jac_deflate, dim3(1), dim3(512), 0, 0, (const v2::SvdDesc*)dd);
+    }
+  } else {
+    const int ne = (n + 1) & ~1;
+    for (int sw = 0; sw < maxsweeps; sw++) {
+      for (int r = 0; r < ne - 1; r++) hipLaunchKernelGGL(v2::k_jac_round, dim3((ne / 2 + 15) / 16, 1), dim3(512), 0, 0, (const v2::SvdDesc*)dd, r);
+      hipLaunchKernelGGL(v2::k_jac_check, dim3(1), dim3(64), 0, 0, (const v2::SvdDesc*)dd, 1);
+    }
   }
   ST2CHK(hipDeviceSynchronize());
+  ST2CHK(hipGetLastError());
   ST2CHK(hipMemcpy(JA.data(), dJA, sizeof(double) * JA.size(), hipMemcpyDeviceToHost));
   ST2CHK(hipMemcpy(hs, dscal, sizeof hs, hipMemcpyDeviceToHost));
   for (int c = 0; c < n; c++) { double s = 0; for (int r = 0; r < m; r++) s += JA[r + (size_t)ldJ * c] * JA[r + (size_t)ldJ * c]; sigma[c] = sqrt(s); }
   *sweeps = hs[6] != 0.0 ? (int)hs[5] : -1;
-  hipFree(dJA); hipFree(dscal); hipFree(dd);
+  hipFree(dJA); hipFree(dscal); hipFree(dd); hipFree(dact);
   return MPBP_OK;
+}
+extern "C" int mpbp_selftest_jacobi_grid(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps, int32_t* sweeps) {
+  return jacobi_selftest(device, m, n, A, sigma, maxsweeps, sweeps, false);
+}
+// the two-level (block) Jacobi of the truncating sweep (v2::k_jac_block) on one m x n matrix, same outputs
+extern "C" int mpbp_selftest_jacobi_block(int32_t device, int32_t m, int32_t n, const double* A, double* sigma, int32_t maxsweeps, int32_t* sweeps) {
+  return jacobi_selftest(device, m, n, A, sigma, maxsweeps, sweeps, true);
 }
 
 // ================================================================================================
@@ -509,6 +551,7 @@ struct ProbPlan {
 };
 
 inline v2::Map2 lin(int64_t s) { return v2::Map2{1 << 30, s, 0}; }
+
 
 }  // namespace
 
@@ -620,7 +663,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     for (int k = 0; k <= i; k++)
       tot += al(plan[k].y_doubles) + al(plan[k].z_doubles) + al(plan[k].e_doubles) + al(plan[k].lf_doubles) + al(2 * v2::auxlay_doubles(nc, nt)) +
              (((size_t)(L + 1) * 12 + 255) & ~size_t(255)) +
-             (trunc2 ? 2 * al(plan[k].c_doubles) + al(plan[k].t1_doubles) + al(plan[k].nt_doubles) + al(plan[k].mt_doubles) + al(plan[k].ja_doubles) + al(plan[k].u_doubles) + 512 : 0);
+             (trunc2 ? 2 * al(plan[k].c_doubles) + al(plan[k].t1_doubles) + al(plan[k].nt_doubles) + al(plan[k].mt_doubles) + al(plan[k].ja_doubles) + al(plan[k].u_doubles) + 512 + (((size_t)plan[k].rr_max * 4 + 255) & ~size_t(255)) + 256 : 0);
     const size_t desc = (size_t)(i + 1) * L * (sizeof(v2::QrProb) * 2 + sizeof(v2::GemmDesc) * (4 + 2 * c->q) + sizeof(v2::EDesc) + sizeof(v2::LfDesc) + sizeof(v2::ScaleDesc) + sizeof(v2::SvdDesc)) + 65536;
     if (i > 0 && tot + desc > budget) break;
     P = i + 1; bytes = tot + desc; nchunk = nc; ntile = nt;
@@ -635,7 +678,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
   // ---- carve the arena
   char* base = c->v2arena.base; size_t used = 0;
   auto take = [&](size_t b) { char* p = base + used; used += (b + 255) & ~size_t(255); return p; };
-  struct Bufs { double *Y, *Z, *E, *aux, *lf; int64_t* lfoff; int32_t* rdim; double *C0, *C1, *T1, *Nt, *Mt, *JA, *U, *scal; };
+  struct Bufs { double *Y, *Z, *E, *aux, *lf; int64_t* lfoff; int32_t* rdim; double *C0, *C1, *T1, *Nt, *Mt, *JA, *U, *scal; int32_t* act; };
   std::vector<Bufs> bf(P);
   for (int i = 0; i < P; i++) {
     bf[i].Y = (double*)take(al(plan[i].y_doubles)); bf[i].Z = (double*)take(al(plan[i].z_doubles));
@@ -647,6 +690,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       bf[i].T1 = (double*)take(al(plan[i].t1_doubles)); bf[i].Nt = (double*)take(al(plan[i].nt_doubles));
       bf[i].Mt = (double*)take(al(plan[i].mt_doubles)); bf[i].JA = (double*)take(al(plan[i].ja_doubles));
       bf[i].U = (double*)take(al(plan[i].u_doubles)); bf[i].scal = (double*)take(512);     // [0] max slot, [1] log c
+      bf[i].act = (int32_t*)take(sizeof(int32_t) * (size_t)std::max(1, plan[i].rr_max));
     }
   }
   // ---- descriptors of all time steps, one upload
@@ -796,7 +840,7 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
         gmt[k] = m;
         q2[k] = v2::QrProb{bf[i].Mt, bf[i].aux, ldM, r1, Rr, std::min(r1, Rr)};
         sv[k] = v2::SvdDesc{bf[i].Mt, bf[i].JA, bf[i].U, Pr.out + (int64_t)t * Pr.ostride, Pr.obond,
-                            ldM, r1, Rr, kc, kp, t, L, trunc2->kind, trunc2->mprime, Pr.cap_out, bf[i].scal};
+                            ldM, r1, Rr, kc, kp, t, L, trunc2->kind, trunc2->mprime, Pr.cap_out, bf[i].scal, bf[i].act};
         v2::GemmDesc cr{};
         cr.S = bf[i].U; cr.X = bf[i].Nt; cr.O = Cnew;
         cr.M = kp; cr.N = (int)Bn; cr.K = Rr;
@@ -835,6 +879,18 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     // ... and only for a handful of problems: with many, one workgroup per problem keeps every CU busy and the 659
     // launches per sweep only add latency (configs[2] shard: 498 s with the grid form on every level, 327 s without)
     const int jac_grid_maxp = [] { const char* e = getenv("MPBP_JACOBI_GRID_MAXP"); return e ? atoi(e) : 4; }();
+    // MPBP_JACOBI_FORM = wg (one workgroup per problem) | grid (one launch per round) | block (two-level, LDS-resident block
+    // pairs); default: wg, and grid for factors of >= 384 columns in batches of <= 4 problems.  The block form was built for
+    // the round-3 review (item 6) and measured on one box each (profiles/r04_jacobi_forms.txt): configs[3] sweep 95.9 against
+    // 95.7 s, configs[4] iteration 26.0 / 27.0 against 24.8 / 26.5 s, a configs[2] block 351 s against 220 s before it got
+    // the deflation of wg::jacobi_rsv.  What makes the one-workgroup form fast is that deflation - on BP factors two thirds
+    // of the columns are numerically null after two sweeps - not the memory level its columns live in; the block form meets
+    // every pair of a block nblk - 1 times per sweep and pays a launch per block round.  It stays selectable and tested.
+    const int jac_form = [] { const char* e = getenv("MPBP_JACOBI_FORM"); return !e ? 0 : (!strcmp(e, "wg") ? 1 : (!strcmp(e, "grid") ? 2 : (!strcmp(e, "block") ? 3 : 0))); }();
+    const int jac_block_min = [] { const char* e = getenv("MPBP_JACOBI_BLOCK_MIN"); return e ? atoi(e) : 96; }();
+    // ... and only while one workgroup per problem leaves most of the chip idle: with a CU per problem for a whole batch the
+    // one-workgroup form is at full occupancy and does fewer rotations (no pair is met twice per sweep)
+    const int jac_block_maxp = [] { const char* e = getenv("MPBP_JACOBI_BLOCK_MAXP"); return e ? atoi(e) : 64; }();
     const size_t svd_lds = sizeof(double) * (32 + (size_t)rrm + (rrm + 1) / 2 + 4);
     HIPCHK(c, hipFuncSetAttribute((const void*)v2::k_svd_trunc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)svd_lds));
     for (int t = 0; t < L; t++) {
@@ -873,29 +929,51 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       // the SVD of the triangular factor: inside one workgroup, or - factors of several hundred columns - as rounds of
       // rotations over the grid (659 launches per sweep at 660 columns: 20+ workgroups rotate at once, a one-workgroup
       // tournament of that size takes 0.3 s per time step)
-      tm.end(2); tm.begin();
       int rrt = 1, k2t = 1;
       for (int i = 0; i < P; i++) { const int Rr = plan[i].kc[t] * probs[i].ny * q; rrt = std::max(rrt, Rr); k2t = std::max(k2t, std::min(Rr, plan[i].rdim[t + 1])); }
-      const bool jgrid = rrt <= 1024 && k2t >= jac_grid_min && P <= jac_grid_maxp;
-      if (!jgrid) hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 0);
+      const v2::SvdDesc* dsvt = dsv + o;
+      tm.end(2); tm.begin();
+      // factors of a hundred columns and more: the two-level (block) Jacobi - block pairs LDS resident, blocks / 2
+      // workgroups per problem, one launch per round of the block tournament (v2::k_jac_block)
+      int jnb = 0;
+      if (jac_form == 3 && k2t >= jac_block_min && rrt <= 1024 && P <= jac_block_maxp) jnb = jac_block_nb(rrt, k2t);
+      const bool jgrid = !jnb && jac_form != 1 && rrt <= 1024 && k2t >= jac_grid_min && P <= jac_grid_maxp;
+      if (jnb) {
+        hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, dsvt, c->d_stats, 1);
+        const size_t jlds = sizeof(double) * ((size_t)(rrt | 1) * 2 * jnb + 32);
+        int nact = k2t;                    // the most active columns of any unconverged problem (read back after every sweep:
+        for (int sweep = 0; sweep < jac_grid_sweeps; sweep++) {      //  the later sweeps run over a fraction of the blocks)
+          const int nblk = (nact + jnb - 1) / jnb, ne = (nblk + 1) & ~1;
+          for (int r = 0; r < std::max(1, ne - 1); r++)
+            hipLaunchKernelGGL(v2::k_jac_block, dim3(ne / 2, P), dim3(512), jlds, st, dsvt, r, jnb);
+          hipLaunchKernelGGL(v2::k_jac_deflate, dim3(P), dim3(512), 0, st, dsvt);
+          int pending[2] = {0, 0};
+          hipLaunchKernelGGL(v2::k_jac_pending2, dim3(1), dim3(256), 0, st, dsvt, P, c->d_counter + 9);
+          HIPCHK(c, hipMemcpyAsync(pending, c->d_counter + 9, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+          HIPCHK(c, hipStreamSynchronize(st));
+          if (pending[0] == 0) break;
+          nact = std::max(2, std::min(nact, pending[1]));
+        }
+        hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, dsvt, c->d_stats, 2);
+      } else if (!jgrid) hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, dsvt, c->d_stats, 0);
       else {
-        hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 1);
+        hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, dsvt, c->d_stats, 1);
         const int ne = (k2t + 1) & ~1;
         // up to 60 sweeps, as the one-workgroup form allows; the host looks at the convergence flags every 4 sweeps
         // (one 4-byte copy) so that the ~6-10 sweeps of the usual case are not followed by 50 sweeps of empty launches
         for (int sweep = 0; sweep < jac_grid_sweeps; sweep++) {
           for (int r = 0; r < ne - 1; r++)
-            hipLaunchKernelGGL(v2::k_jac_round, dim3((ne / 2 + 15) / 16, P), dim3(512), 0, st, (const v2::SvdDesc*)(dsv + o), r);
-          hipLaunchKernelGGL(v2::k_jac_check, dim3((P + 63) / 64), dim3(64), 0, st, (const v2::SvdDesc*)(dsv + o), P);
+            hipLaunchKernelGGL(v2::k_jac_round, dim3((ne / 2 + 15) / 16, P), dim3(512), 0, st, dsvt, r);
+          hipLaunchKernelGGL(v2::k_jac_check, dim3((P + 63) / 64), dim3(64), 0, st, dsvt, P);
           if ((sweep & 3) == 3) {
             int pending = 0;
-            hipLaunchKernelGGL(v2::k_jac_pending, dim3(1), dim3(256), 0, st, (const v2::SvdDesc*)(dsv + o), P, c->d_counter + 9);
+            hipLaunchKernelGGL(v2::k_jac_pending, dim3(1), dim3(256), 0, st, dsvt, P, c->d_counter + 9);
             HIPCHK(c, hipMemcpyAsync(&pending, c->d_counter + 9, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             if (pending == 0) break;
           }
         }
-        hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, (const v2::SvdDesc*)(dsv + o), c->d_stats, 2);
+        hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, dsvt, c->d_stats, 2);
       }
       tm.end(3); tm.begin();
       hipLaunchKernelGGL(v2::k_gemm, dim3(std::min(1024, (maxNc + 127) / 128), P), dim3(512), 0, st, (const v2::GemmDesc*)(dcr + o));

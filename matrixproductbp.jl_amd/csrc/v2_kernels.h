@@ -1191,7 +1191,8 @@ __host__ __device__ inline int jac_ld(int m) { return (m + 15) & ~15; }
 struct SvdDesc {
   const double* Mt; double* JA; double* U; double* core; int32_t* obond;   // obond: the output train's bond table
   int32_t ldM, r1, Rr, kc, kp, t, L, kind, mprime, cap_out;
-  double* scal;    // per-problem scalars of the multi-launch Jacobi: [3] ||R||_F^2, [4] worst cos^2 of the sweep (bits), [5] sweeps, [6] done
+  double* scal;    // per-problem scalars of the multi-launch Jacobi: [3] ||R||_F^2, [4] worst cos^2 of the sweep (bits), [5] sweeps, [6] done, [7] active columns
+  int32_t* act;    // block Jacobi: the columns still in the tournament (numerically null ones leave it, as in wg::jacobi_rsv); may be null (k_jac_round)
 };
 __device__ __forceinline__ void atomic_max_pos(unsigned long long* addr, double v) { atomicMax(addr, (unsigned long long)__double_as_longlong(v)); }
 
@@ -1223,7 +1224,8 @@ __global__ void __launch_bounds__(512) k_svd_trunc(const SvdDesc* descs, EngStat
     __syncthreads();
   }
   if (mode == 1) {
-    if (tid == 0) { D.scal[3] = fro2; D.scal[4] = 0.0; D.scal[5] = 0.0; D.scal[6] = (k2 < 2) ? 1.0 : 0.0; }
+    if (tid == 0) { D.scal[3] = fro2; D.scal[4] = 0.0; D.scal[5] = 0.0; D.scal[6] = (k2 < 2) ? 1.0 : 0.0; D.scal[7] = (double)k2; }
+    if (D.act) for (int c = tid; c < k2; c += 512) D.act[c] = c;
     return;
   }
   int sw;
@@ -1335,6 +1337,178 @@ __global__ void k_jac_check(const SvdDesc* descs, int nprob) {
   D.scal[5] += 1.0;
   if (D.scal[4] < 1e-16) D.scal[6] = 1.0;
   D.scal[4] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Two-level (block) one-sided Jacobi: the columns of the factor are cut into blocks of `nb`; a launch is one round of the
+// round-robin tournament of the BLOCKS, every workgroup takes one block pair, holds its 2 nb columns in LDS (odd leading
+// dimension), runs ONE sweep over all pairs of those columns there - same rotation, thresholds and null test as
+// wg::jacobi_rsv - and writes them back.  The one-workgroup form keeps a 160 x 160 factor in HBM and touches every column
+// two to three times per round through the CU's L1 (~3 us per round, 159 rounds per sweep, ONE CU per problem whatever the
+// batch); here a round is ~0.6 us of LDS traffic, a sweep is (blocks - 1) launches, and a problem occupies blocks / 2 CUs.
+// Pairs inside a block meet in every round of the block tournament (more rotations per sweep, fewer sweeps).
+// k_jac_check closes a sweep as for k_jac_round.  grid (block pairs, nprob), 512 threads, dynamic LDS (m | 1) * 2 nb + 32 doubles.
+// ------------------------------------------------------------------------------------------------------------------
+template <int LP>     // lanes per column pair: 8 or 16 (one DPP row)
+__device__ __forceinline__ double jac_lds_pair(ldbl* ap, ldbl* aq, int sub, int m, double tol, double nul) {
+  constexpr int JC = 12;                     // rows per lane held in registers at a time
+  const int rpl = (m + LP - 1) / LP;
+  double al = 0, be = 0, ga = 0;
+  double x[JC], y[JC];
+  auto loadc = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < JC; i++) {
+      const int r = sub + (i0 + i) * LP;
+      const bool ok = r < m;
+      const int rc = ok ? r : sub;
+      const double xv = ap[rc], yv = aq[rc];
+      x[i] = ok ? xv : 0.0; y[i] = ok ? yv : 0.0;
+    }
+  };
+  for (int i0 = 0; i0 < rpl; i0 += JC) {
+    loadc(i0);
+#pragma unroll
+    for (int i = 0; i < JC; i++) { al += x[i] * x[i]; be += y[i] * y[i]; ga += x[i] * y[i]; }
+  }
+  if (LP == 16) { al += dpp64<0x140>(al); be += dpp64<0x140>(be); ga += dpp64<0x140>(ga); }      // row_mirror: lanes i, 15 - i
+  al += dpp64<0x141>(al); be += dpp64<0x141>(be); ga += dpp64<0x141>(ga);
+  al += dpp64<0x4E>(al); be += dpp64<0x4E>(be); ga += dpp64<0x4E>(ga);
+  al += dpp64<0xB1>(al); be += dpp64<0xB1>(be); ga += dpp64<0xB1>(ga);
+  if (!(ga * ga > (tol * tol) * (al * be) && al > nul && be > nul)) return 0.0;
+  double c, s;
+  jac_cs(al, be, ga, c, s);
+  for (int i0 = 0; i0 < rpl; i0 += JC) {
+    if (rpl > JC) loadc(i0);
+#pragma unroll
+    for (int i = 0; i < JC; i++) {
+      const int r = sub + (i0 + i) * LP;
+      if (r < m) { ap[r] = c * x[i] - s * y[i]; aq[r] = s * x[i] + c * y[i]; }
+    }
+  }
+  return ga * ga / (al * be);
+}
+// one sweep over all pairs of the nc columns of an LDS-resident m x nc matrix (512 threads); the largest cos^2 met, per lane
+template <int LP>
+__device__ __forceinline__ double jac_lds_sweep(ldbl* A, int lda, int m, int nc, double tol, double nul) {
+  const int tid = threadIdx.x, sub = tid & (LP - 1), grp = tid / LP;
+  const int ne = (nc + 1) & ~1, npairs = ne / 2;
+  double worst = 0.0;
+  for (int round = 0; round < ne - 1; round++) {
+    for (int pb = 0; pb < npairs; pb += 512 / LP) {
+      const int pi = pb + grp;
+      if (pi < npairs) {
+        int p, q;
+        if (pi == 0) { p = ne - 1; q = round; }
+        else {
+          p = round + pi; p -= (p >= ne - 1) ? (ne - 1) : 0;
+          q = round + (ne - 1) - pi; q -= (q >= ne - 1) ? (ne - 1) : 0;
+        }
+        if (p > q) { const int t_ = p; p = q; q = t_; }
+        if (q < nc) worst = fmax(worst, jac_lds_pair<LP>(A + (long)lda * p, A + (long)lda * q, sub, m, tol, nul));
+      }
+    }
+    __syncthreads();
+  }
+  return worst;
+}
+__global__ void __launch_bounds__(512) k_jac_block(const SvdDesc* descs, int round, int nb) {
+  const SvdDesc D = descs[blockIdx.y];
+  if (D.scal[6] != 0.0) return;                      // converged
+  const int m = D.Rr, n = (int)D.scal[7];            // the active columns, through D.act
+  if (n < 2) return;
+  const int nblk = (n + nb - 1) / nb, ne = (nblk + 1) & ~1;
+  const int pi = blockIdx.x;
+  if (pi >= ne / 2) return;
+  int bp, bq;
+  if (ne == 2) { if (round > 0) return; bp = 0; bq = 1; }
+  else {
+    if (round >= ne - 1) return;
+    if (pi == 0) { bp = ne - 1; bq = round; }
+    else {
+      bp = round + pi; bp -= (bp >= ne - 1) ? (ne - 1) : 0;
+      bq = round + (ne - 1) - pi; bq -= (bq >= ne - 1) ? (ne - 1) : 0;
+    }
+    if (bp > bq) { const int t_ = bp; bp = bq; bq = t_; }
+  }
+  // a lone block (nblk == 1) still needs its inner sweep; the dummy player of an odd tournament sits out with its partner
+  // EXCEPT that the partner's inner pairs are covered by its other rounds
+  const bool lone = nblk == 1;
+  if (!lone && bq >= nblk) return;
+  extern __shared__ __attribute__((aligned(16))) double jb_lds_[];
+  ldbl* A = (ldbl*)jb_lds_;
+  const int lda = m | 1;
+  const int ldJ = jac_ld(m);
+  gdbl* JA = (gdbl*)D.JA;
+  const int c0p = bp * nb, ncp = min(nb, n - c0p);
+  const int c0q = lone ? 0 : bq * nb, ncq = lone ? 0 : min(nb, n - c0q);
+  const int nc = ncp + ncq;
+  const int tid = threadIdx.x;
+  // columns -> LDS (two rows per access: the HBM columns start on 128-byte lines, m is even on this path or the tail is scalar)
+  const int32_t* act = D.act;
+  for (int idx = tid; idx < nc * m; idx += 512) {
+    const int c = idx / m, r = idx - c * m;
+    const int gc = act[c < ncp ? c0p + c : c0q + (c - ncp)];
+    A[r + (long)lda * c] = JA[r + (int64_t)ldJ * gc];
+  }
+  __syncthreads();
+  const double nul = 1e-28 * D.scal[3], tol = 1e-15;
+  double worst;
+  if ((nc + 1) / 2 * 16 <= 512) worst = jac_lds_sweep<16>(A, lda, m, nc, tol, nul);
+  else worst = jac_lds_sweep<8>(A, lda, m, nc, tol, nul);
+  for (int idx = tid; idx < nc * m; idx += 512) {
+    const int c = idx / m, r = idx - c * m;
+    const int gc = act[c < ncp ? c0p + c : c0q + (c - ncp)];
+    JA[r + (int64_t)ldJ * gc] = A[r + (long)lda * c];
+  }
+  worst = wave_max(worst);
+  if ((tid & 63) == 0 && worst > 0.0) atomicMax((unsigned long long*)(D.scal + 4), (unsigned long long)__double_as_longlong(worst));
+}
+
+// Closes a sweep of the block Jacobi: the convergence test of wg::jacobi_rsv (the largest cos^2 met < 1e-16), then its
+// deflation - a column whose squared norm is below 1e-28 ||A||_F^2 is numerically null, never rotates again and leaves
+// the tournament (the factors here have singular values over twenty decades: most columns are gone after two sweeps, and
+// the later sweeps run over a fraction of the blocks).  grid (nprob), 512 threads.
+__global__ void __launch_bounds__(512) k_jac_deflate(const SvdDesc* descs) {
+  const SvdDesc D = descs[blockIdx.x];
+  if (D.scal[6] != 0.0) return;
+  __shared__ int keep_[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = D.Rr, n = (int)D.scal[7];
+  const bool conv = D.scal[4] < 1e-16;
+  if (!conv) {
+    const int ldJ = jac_ld(m);
+    const gdbl* JA = (const gdbl*)D.JA;
+    const double nul = 1e-28 * D.scal[3];
+    for (int i = wave; i < n; i += 8) {                         // a wave per column
+      const gdbl* ac = JA + (int64_t)ldJ * D.act[i];
+      double s2 = 0.0;
+      for (int r = lane; r < m; r += 64) s2 += ac[r] * ac[r];
+      s2 = wave_sum(s2);
+      if (lane == 0) keep_[i] = (s2 > nul) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    D.scal[5] += 1.0;
+    if (conv) D.scal[6] = 1.0;
+    else {
+      int w = 0;
+      for (int i = 0; i < n; i++) if (keep_[i]) D.act[w++] = D.act[i];
+      D.scal[7] = (double)w;
+      if (w < 2) D.scal[6] = 1.0;
+    }
+    D.scal[4] = 0.0;
+  }
+}
+// pending[0] = problems of the batch whose block Jacobi has not converged, pending[1] = the most active columns among them
+__global__ void k_jac_pending2(const SvdDesc* descs, int nprob, int* pending) {
+  __shared__ int cnt, mx;
+  if (threadIdx.x == 0) { cnt = 0; mx = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nprob; i += blockDim.x)
+    if (descs[i].scal[6] == 0.0) { atomicAdd(&cnt, 1); atomicMax(&mx, (int)descs[i].scal[7]); }
+  __syncthreads();
+  if (threadIdx.x == 0) { pending[0] = cnt; pending[1] = mx; }
 }
 
 // *pending = number of problems whose Jacobi has not converged yet (the host polls it every few sweeps); one workgroup

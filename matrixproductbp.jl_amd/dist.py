@@ -26,20 +26,36 @@ def node_costs(nbr_ptr, q, max_bond, T, nstates=None):
     return np.array([by_deg[int(d)] for d in deg])
 
 
-# Measured rates behind `node_times` (MI355X; profiles/r03_config2_all_shards.txt: every one of the 8 node blocks of configs[2]
-# run on one GPU, one saturated sweep each; r03_bench.json):
-#   RATE_WG        executed flop rate of the workgroup engine at configs[1]-sized batches
-#   RATE_GRID      executed flop rate of the batched gauge sweep when many problems share a launch (configs[2] levels)
-#   LEVEL_LATENCY  seconds per time step of a dependency level that holds ONE hub's problem alone: the levels of a node's
-#                  3z-2 cavity products (CavityTools order) deeper than a typical node's are not filled by other nodes, and a
-#                  single problem advances at the latency of its launch sequence, not at the flop rate.  Levels of different
-#                  hubs of one rank run in the SAME launches, so the rank pays for its deepest node only (max, not sum).
-# RATE_GRID and LEVEL_LATENCY are the least-squares fit of  time = flops / RATE_GRID + levels(z_max) T LEVEL_LATENCY  to the eight
-# blocks of the shipped cut measured on the round's FINAL build (222.3 ... 235.3 s, z_max 9 ... 12): residuals within 2.2 %.
-# (The same fit on the build before the line-aligned Jacobi of the truncating sweep gave 18.0 TFLOP/s and 30 ms.)
-RATE_WG = 20e12
-RATE_GRID = 18.6e12
-LEVEL_LATENCY = 19.5e-3
+# Measured rates behind `node_times` - NOT constants of the source: they live in time_model.json next to this file and are
+# regenerated from measurements by tools/fit_time_model.py (round-3 review item 7: a fit to one build drifts with every kernel
+# change).  The file holds
+#   rate_wg_flops     executed flop rate of the workgroup engine at configs[1]-sized batches (bench.py's roofline.achieved)
+#   rate_grid_flops   executed flop rate of the batched gauge sweep when many problems share a launch (configs[2] levels)
+#   level_latency_s   seconds per time step of a dependency level that holds ONE hub's problem alone: the levels of a node's
+#                     3z-2 cavity products (CavityTools order) deeper than a typical node's are not filled by other nodes, and a
+#                     single problem advances at the latency of its launch sequence, not at the flop rate.  Levels of different
+#                     hubs of one rank run in the SAME launches, so the rank pays for its deepest node only (max, not sum).
+#   config2_blocks_s  the measurements behind the last two: every node block of the shipped 8-way cut of configs[2], alone on
+#                     one MI355X, seconds per saturated sweep (bench.py --config 2 --shard-of 8 --shard-index k --saturate);
+#                     rate_grid_flops and level_latency_s are the least-squares fit of
+#                         time = flops / rate_grid + levels(z_max) T level_latency
+#                     to them (tests/test_dist.py pins the fit to the table at 4 %).
+def _load_time_model():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "time_model.json")) as fh:
+        return json.load(fh)
+
+
+TIME_MODEL = _load_time_model()
+RATE_WG = float(TIME_MODEL["rate_wg_flops"])
+RATE_GRID = float(TIME_MODEL["rate_grid_flops"])
+LEVEL_LATENCY = float(TIME_MODEL["level_latency_s"])
+
+
+def config2_measured_blocks():
+    """{(lo, hi): seconds per saturated sweep} of the node blocks the time model was fitted to."""
+    return {tuple(int(v) for v in k.split(",")): float(s) for k, s in TIME_MODEL["config2_blocks_s"].items()}
 
 
 def node_times(nbr_ptr, q, max_bond, T, nstates=None, grid=None):

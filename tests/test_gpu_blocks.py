@@ -220,3 +220,27 @@ def test_jacobi_grid_singular_values(m, n):
     ref = np.linalg.svd(A, compute_uv=False)
     got = np.sort(sig)[::-1]
     assert np.abs(got - ref).max() < 1e-13 * ref[0]
+
+
+# shapes: one lone block (n <= nb), two blocks, an odd number of blocks with a ragged last block, configs[3]'s 160 x 160
+# factor (eight blocks of 20), configs[2] hub factors (360 x 360; 660 x 500: block pairs of 14 columns just fit the LDS)
+@pytest.mark.parametrize("m,n", [(4, 4), (9, 7), (40, 40), (80, 33), (96, 96), (161, 130), (160, 160), (360, 360), (660, 500)])
+def test_jacobi_block_singular_values_and_orthogonality(m, n):
+    """The two-level (block) one-sided Jacobi of the batched truncating sweep (v2::k_jac_block: column blocks, block pairs
+    rotated LDS resident, one launch per round of the block tournament) on the matrices the engine meets - transposed
+    triangular factors with singular values over 22 decades: LAPACK's singular values, within the sweep budget."""
+    rng = np.random.default_rng(33)
+    U, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.logspace(0, -22, n)
+    Mx = (U[:, :n] * s) @ V.T
+    A = np.asfortranarray(np.linalg.qr(Mx.T, mode="r").T.copy())
+    sig = np.zeros(n)
+    sw = C.c_int32(0)
+    lib = mpbp_amd._lib.lib()
+    rc = lib.mpbp_selftest_jacobi_block(0, A.shape[0], n, _dp(A), _dp(sig), 30, C.byref(sw))
+    assert rc == 0, lib.mpbp_last_error(None)
+    assert 0 < sw.value <= 14, sw.value
+    ref = np.linalg.svd(A, compute_uv=False)
+    got = np.sort(sig)[::-1]
+    assert np.abs(got - ref).max() < 1e-13 * ref[0]
