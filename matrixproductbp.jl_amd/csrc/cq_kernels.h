@@ -742,8 +742,10 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
 // operands - every ds_read feeds two MFMAs, 256 + 256 registers, no spill - 37-38 against 38-40 TFLOP/s: the LDS operand
 // stream is not what a wave waits for; (ii) the 256 LDS address adds of phase C hoisted (kept): no change - nor is VALU
 // issue; (iii) no global traffic at all (-DCQ_NO_GLOBAL): 44 TFLOP/s = 23 us per tile and wave against 14.7 us of MFMA issue
-// at 2.4 GHz, 20.8 us with half the CUs busy - the stream runs at ~77 % of MFMA issue in CYCLES and the rest is the clock
-// the part sustains under fp64 MFMA load; (iv) eight-wave workgroups (two waves per SIMD, 256 registers, spills): 30-33.)
+// at 2.4 GHz, 20.8 us with half the CUs busy; the shader clock under this load is 2.26 GHz (s_memtime against s_memrealtime,
+// -DCQ_UPROF), so a wave spends ~84 cycles per 64-cycle MFMA whatever stands between them; (iv) the next row group's LDS
+// reads forced right behind the first MFMA of a group (sched_group_barrier; the compiler issues them after the last one, 64
+// cycles before their use): no change; (v) eight-wave workgroups (two waves per SIMD, 256 registers, spills): 30-33 TFLOP/s.)
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int level, int slot, int node, int tg, int tpg,
@@ -761,6 +763,9 @@ __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, i
   constexpr int nwave = NT >> 6;
 #ifdef CQ_UPROF
   const unsigned long long cq_wg_t0 = __builtin_readcyclecounter();
+  const unsigned long long cq_wg_r0 = __builtin_amdgcn_s_memrealtime();
+  struct ClockNote { unsigned long long c0, r0; bool on; __device__ ~ClockNote() { if (on) { atomicAdd(&cq_uprof[5], __builtin_readcyclecounter() - c0); atomicAdd(&cq_uprof[7], __builtin_amdgcn_s_memrealtime() - r0); } } };
+  ClockNote cq_note{cq_wg_t0, cq_wg_r0, threadIdx.x == 0};          // [5] shader-clock cycles, [7] 100 MHz ticks of the workgroup
 #endif
   // The node's image (148 KB) -> LDS by LDS-DMA: 148 wave-instructions of 1 KiB (global_load_lds_dwordx4, no register
   // staging), all in flight at once, and the wave's FIRST tile is requested behind them before anybody waits.  (As a plain

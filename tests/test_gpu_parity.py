@@ -579,6 +579,46 @@ def test_full_size_config2_properties():
     assert abs(M.bethe_free_energy(bp)) < 1e-2 * N
 
 
+def test_full_size_config1_sampled_node_updates_match_oracle():
+    """BASELINE configs[1] at FULL size (SIS on random_regular_graph(3, 1024, seed=0), T=50, TruncBond(20)) against the oracle
+    where the oracle can follow: after four sweeps on the device (bonds at the cap everywhere) the in-messages of two nodes are
+    read back, the device does its fifth sweep, and the oracle (reference algorithm: two SVD sweeps per `op`,
+    recursive_bp_factor.jl:146-165) updates those two nodes from the very same messages - belief and free-energy term of each
+    at the contract's 1e-6 (observed ~1e-12).  The property test above cannot see a wrong-but-normalised result; this can."""
+    import ctypes as C
+    N, T, Mb = 1024, 50, 20
+    A = nx.to_numpy_array(nx.random_regular_graph(3, N, seed=0), nodelist=range(N))
+    gam, lam, rho = 0.1, 0.1, 0.05
+    phi = [[np.array([1 - gam, gam]) if t == 0 else np.ones(2) for t in range(T + 1)] for _ in range(N)]
+    g = M.IndexedBiDiGraph(A)
+    bp = M.mpbp(g, [[M.SISFactor(lam, rho)] * (T + 1)] * N, 2, T, phi=phi, max_bond=Mb)
+    allnodes = np.arange(N, dtype=np.int32)
+    for _ in range(4):
+        M.onebpiter(bp, allnodes, M.TruncBond(Mb))
+    assert bp.bonds().max() == Mb
+    ptr, ine, oute = g.nbr_arrays()
+    sample = [5, 777]
+    snap = {}
+    for i in sample:
+        e_in = [int(ine[p_]) for p_ in range(ptr[i], ptr[i + 1])]
+        msgs = bp.get_messages(edges=e_in)
+        snap[i] = [(e, msgs[e]) for e in e_in]
+        assert max(c.shape[0] for _, m in snap[i] for c in m) == Mb            # saturated inputs
+    M.onebpiter(bp, allnodes, M.TruncBond(Mb))
+    b = np.array(M.beliefs(bp))
+    f = np.zeros(N)
+    bp._L.mpbp_free_energy(bp._h, f.ctypes.data_as(C.POINTER(C.c_double)))
+    obp = O.mpbp(O.IndexedBiDiGraph(A), [[OF.SISFactor(lam, rho)] * (T + 1)] * N, [2] * N, T, phi=phi)
+    for i in sample:
+        for e, m in snap[i]:
+            obp.mu[e] = OT.TensorTrain([np.array(c) for c in m])
+        O.onebpiter(obp, i, OT.TruncBond(Mb))
+        ob = np.array(O.beliefs(obp)[i])
+        assert np.abs(b[i] - ob).max() <= 1e-6 * max(1.0, np.abs(ob).max()), (i, np.abs(b[i] - ob).max())
+        assert (np.abs(b[i] - ob) / np.maximum(ob, 1e-300)).max() < 1e-6
+        assert abs(f[i] - obp.f[i]) <= 1e-6 * max(1.0, abs(obp.f[i])), (i, f[i], obp.f[i])
+
+
 def _check_node_properties(bp, nodes, Mb, st):
     assert st.nan_flag == 0 and st.capacity_flag == 0 and st.jacobi_not_converged == 0
     b = np.array(M.beliefs(bp))[nodes]

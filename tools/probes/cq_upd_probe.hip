@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
         unsigned long long h[8];
         hipMemcpyFromSymbol(h, HIP_SYMBOL(cq::cq_uprof), sizeof h);
         const double tiles = (double)ntl * n, wvs = (double)h[6];
+        printf("    shader clock while the workgroups run: %.0f MHz (s_memtime cycles / s_memrealtime 100 MHz ticks)\n", (double)h[5] / (double)h[7] * 100.0);
         printf("    per wave: image + first request + barrier %7.0f cycles;  per tile: wait %6.0f  phase A %6.0f  phase B %6.0f  phase C %6.0f  (MFMA issue: 16384 / 2560 / 16384)\n",
                h[0] / wvs, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles);
 #endif
