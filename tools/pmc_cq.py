@@ -47,8 +47,12 @@ def main():
     for shape in shapes:
         rows, cols, nprob = (int(v) for v in shape.split("x"))
         agg = collections.defaultdict(float)
-        for c in ("FETCH_SIZE", "WRITE_SIZE", "MFMA"):
-            for r in csv.DictReader(open(f"gpurun_out/{pre}_pmc_{shape}_{c}/p_counter_collection.csv")):
+        import os
+        for c in ("FETCH_SIZE", "WRITE_SIZE", "MFMA", "LDS"):
+            f = f"gpurun_out/{pre}_pmc_{shape}_{c}/p_counter_collection.csv"
+            if c == "LDS" and not os.path.exists(f):
+                continue
+            for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 if name.startswith("cq::"):
                     agg[(name, r["Counter_Name"])] += float(r["Counter_Value"])
@@ -67,7 +71,8 @@ def main():
             busy, sq = agg[(k, "SQ_VALU_MFMA_BUSY_CYCLES")], agg[(k, "SQ_BUSY_CYCLES")]
             res["kernels"][k] = {"fetch_bytes_per_qr": agg[(k, "FETCH_SIZE")] * 2048 / per, "write_bytes_per_qr": agg[(k, "WRITE_SIZE")] * 1024 / per,
                                  "mfma_flops_per_qr": agg[(k, "SQ_INSTS_VALU_MFMA_F64")] * 2048 / per,
-                                 "mfma_pipe_busy": busy / (sq / 32.0 * 1024.0) if sq else None}
+                                 "mfma_pipe_busy": busy / (sq / 32.0 * 1024.0) if sq else None,
+                                 "lds_bank_conflict_share": (agg[(k, "SQ_LDS_BANK_CONFLICT")] / agg[(k, "SQ_LDS_IDX_ACTIVE")]) if agg.get((k, "SQ_LDS_IDX_ACTIVE")) else None}
         out["shapes"][shape] = res
         print(f"{shape}: {res['bytes_per_qr'] / 1e9:.2f} GB per QR (matrix {res['matrix_bytes'] / 1e6:.0f} MB, model {res['model_bytes_per_qr'] / 1e9:.2f} GB, "
               f"x{res['measured_over_model']:.2f}); executed {res['executed_mfma_flops_per_qr'] / 1e9:.1f} Gflop = {res['executed_over_householder']:.2f} x Householder; "
