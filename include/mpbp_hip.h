@@ -149,6 +149,15 @@ int mpbp_set_factor(mpbp_ctx* ctx, int32_t node, int32_t deg, const int32_t* nst
  */
 int mpbp_set_generic_factor(mpbp_ctx* ctx, int32_t node, int32_t deg, int32_t nt, const double* w);
 
+/* Heterogeneous `nstates(bp, i)` (reference src/mpbp.jl:22-26: every node has its own number of states q_i; the messages
+ * of edge i->j are MPEM2s over q_i x q_j, src/recursive_bp_factor.jl:155).  `mpbp_desc::q` is the LARGEST q_i; node i uses
+ * its first q_node[i] states and the others are padding that carries exactly zero weight: the library zeroes phi, psi
+ * and the message tables there, so normalisations, beliefs, pair beliefs and free energies are those of the unpadded
+ * model (factor tables are passed for q states; their entries on padding states are ignored).  Messages are reset to the
+ * reference's initial state (uniform over the real states).  Stored bond dimensions may exceed the reference's by
+ * directions of zero weight where the reference's bound q_i q_j (not the truncation) limits a bond. */
+int mpbp_set_node_states(mpbp_ctx* ctx, const int32_t* q_node /* [n_nodes], 1 <= q_node[i] <= q */);
+
 /* phi[i][t][x]: double[q][T+1][n_nodes] (x fastest)  - `bp.ϕ`, reference src/mpbp.jl:4 */
 int mpbp_set_phi(mpbp_ctx* ctx, const double* phi);
 /* psi[e][t][x_src][x_dst]: double[q][q][T+1][n_edges] (x_src fastest) - `bp.ψ`, src/mpbp.jl:5 */

@@ -83,8 +83,11 @@ function generic_table(w::BPFactor, q::Int, deg::Int)
 end
 
 function HIPBackend(bp::MPBP; max_bond::Integer, device::Integer=0)
-    g = bp.g; N = nv(g); E = ne(g); T = getT(bp); q = nstates(bp.b[1])
-    all(nstates(b) == q for b in bp.b) || error("heterogeneous nstates is not on the device path")
+    # nstates may differ from node to node (src/mpbp.jl:22-26): the device works with q = the largest and treats the states
+    # beyond nstates(bp, i) as padding of zero weight (mpbp_set_node_states); factor tables are evaluated for all q states
+    # (a factor that throws on a state it does not know has to be wrapped), ϕ / ψ are zero-padded
+    g = bp.g; N = nv(g); E = ne(g); T = getT(bp)
+    qn = Int32[nstates(b) for b in bp.b]; q = Int(maximum(qn))
     nbr_ptr, in_edge, out_edge = neighbour_tables(g)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve nbr_ptr in_edge out_edge begin
@@ -94,6 +97,7 @@ function HIPBackend(bp::MPBP; max_bond::Integer, device::Integer=0)
     end
     be = HIPBackend(h[], N, E, T, q, Stats())
     finalizer(b -> ccall((:mpbp_destroy, LIB), Cvoid, (Ptr{Cvoid},), b.h), be)
+    any(qn .!= q) && check(ccall((:mpbp_set_node_states, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}), be.h, qn), be.h)
     for i in 1:N
         deg = Int(nbr_ptr[i+1] - nbr_ptr[i])
         same = all(w == bp.w[i][1] for w in bp.w[i])
@@ -111,8 +115,9 @@ function HIPBackend(bp::MPBP; max_bond::Integer, device::Integer=0)
                     (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                     be.h, i - 1, deg, ny, length(ts), cat(2), cat(3), cat(4), cat(5)), be.h)
     end
-    ϕ = Float64[bp.ϕ[i][t][x] for x in 1:q, t in 1:T+1, i in 1:N]
-    ψ = Float64[bp.ψ[e][t][xi, xj] for xi in 1:q, xj in 1:q, t in 1:T+1, e in 1:E]
+    ends = [(src(e), dst(e)) for e in edges(g)]                  # edge ids in the order of idx(e)
+    ϕ = Float64[x <= qn[i] ? bp.ϕ[i][t][x] : 0.0 for x in 1:q, t in 1:T+1, i in 1:N]
+    ψ = Float64[(xi <= qn[ends[e][1]] && xj <= qn[ends[e][2]]) ? bp.ψ[e][t][xi, xj] : 0.0 for xi in 1:q, xj in 1:q, t in 1:T+1, e in 1:E]
     check(ccall((:mpbp_set_phi, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), be.h, ϕ), be.h)
     check(ccall((:mpbp_set_psi, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), be.h, ψ), be.h)
     push_messages!(be, bp)

@@ -53,7 +53,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["mpbp_create", "mpbp_destroy", "mpbp_last_error", "mpbp_slab_layout", "mpbp_slab_pointers",
-           "mpbp_set_factor", "mpbp_set_generic_factor", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
+           "mpbp_set_factor", "mpbp_set_generic_factor", "mpbp_set_node_states", "mpbp_set_phi", "mpbp_set_psi", "mpbp_set_messages", "mpbp_get_bonds",
            "mpbp_get_messages", "mpbp_reset_messages", "mpbp_sweep", "mpbp_beliefs", "mpbp_get_belief_train", "mpbp_pair_beliefs",
            "mpbp_free_energy", "mpbp_logz", "mpbp_allgather_slots", "mpbp_twovar_marginals", "mpbp_set_profiling", "mpbp_phase_profile", "mpbp_selftest_gemm", "mpbp_selftest_qr", "mpbp_selftest_qr_bench",
            "mpbp_selftest_jacobi_bench", "mpbp_selftest_svd", "mpbp_selftest_qr_batched", "mpbp_selftest_qr_batched_seq", "mpbp_selftest_jacobi_grid", "mpbp_selftest_jacobi_block"]
@@ -117,6 +117,7 @@ def lib():
     dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
     L.mpbp_set_factor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ip, C.c_int32, dp, dp, dp, dp]
     L.mpbp_set_generic_factor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, dp]
+    L.mpbp_set_node_states.argtypes = [C.c_void_p, ip]
     L.mpbp_set_phi.argtypes = [C.c_void_p, dp]
     L.mpbp_set_psi.argtypes = [C.c_void_p, dp]
     L.mpbp_set_messages.argtypes = [C.c_void_p, ip, lp, dp]

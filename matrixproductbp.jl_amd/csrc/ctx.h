@@ -62,6 +62,10 @@ struct mpbp_ctx {
   bool periodic = false;          // time-periodic chains (mpbp_desc::periodic)
   int ct_factor() const { return periodic ? q * q : q; }   // bond factor of the MPEM3 -> MPEM2 embedding
   std::vector<int> nbr_ptr, in_edge, out_edge, slot_of_edge;
+  // heterogeneous nstates(bp, i) (reference src/mpbp.jl: q per node): node i uses the first qnode[i] <= q states, the others
+  // are padding that carries exactly zero weight (mpbp_set_node_states); edge_src / edge_dst: end nodes of every edge
+  std::vector<int> qnode, edge_src, edge_dst;
+  bool hetero_q = false;
   std::vector<NodeFactor> fac;
   std::vector<double> phi, psi;           // host copies (ABI layouts)
   bool own_cores = false, own_bonds = false, own_stream = false;

@@ -36,6 +36,10 @@ extern "C" int mpbp_create(mpbp_ctx** out, const mpbp_desc* d) {
     if (c->slot_of_edge[e] < 0 || c->slot_of_edge[e] >= c->nslots) { g_create_error = "slot_of_edge out of range"; delete c; return MPBP_EINVAL; }
   }
   c->fac.resize(c->N);
+  c->qnode.assign(c->N, c->q);
+  c->edge_src.assign(c->E, -1); c->edge_dst.assign(c->E, -1);
+  for (int i = 0; i < c->N; i++)
+    for (int p = c->nbr_ptr[i]; p < c->nbr_ptr[i + 1]; p++) { c->edge_dst[c->in_edge[p]] = i; c->edge_src[c->out_edge[p]] = i; }
   c->core_stride = (int64_t)c->cap * c->cap * c->q * c->q;
   c->slot_doubles = c->core_stride * c->L;
   hipError_t e = hipSetDevice(c->device);
@@ -193,6 +197,19 @@ extern "C" int mpbp_set_generic_factor(mpbp_ctx* c, int32_t node, int32_t deg, i
   return MPBP_OK;
 }
 
+extern "C" int mpbp_set_node_states(mpbp_ctx* c, const int32_t* q_node) {
+  if (!c || !q_node) return MPBP_EINVAL;
+  bool het = false;
+  for (int i = 0; i < c->N; i++) {
+    if (q_node[i] < 1 || q_node[i] > c->q) return c->fail(MPBP_EINVAL, "node %d: nstates %d outside 1 .. q = %d", i, q_node[i], c->q);
+    het = het || q_node[i] != c->q;
+  }
+  c->qnode.assign(q_node, q_node + c->N);
+  c->hetero_q = het;
+  c->tables_dirty = true;
+  return mpbp_reset_messages(c);          // the initial messages are uniform over the REAL states of both end nodes
+}
+
 extern "C" int mpbp_set_phi(mpbp_ctx* c, const double* phi) {
   if (!c || !phi) return MPBP_EINVAL;
   c->phi.assign(phi, phi + (size_t)c->q * c->L * c->N); c->tables_dirty = true; return MPBP_OK;
@@ -264,6 +281,15 @@ extern "C" int mpbp_reset_messages(mpbp_ctx* c) {
   for (int t = 0; t < L; t++) for (int s = 0; s < qq; s++) slot[(int64_t)t * c->core_stride + s] = 1.0 / qq;
   std::vector<int32_t> b(L + 1, 1);
   for (int e = 0; e < c->E; e++) {
+    if (c->hetero_q) {
+      // flat_mpem2(q_src, q_dst, T) of the reference (src/mpbp.jl:66): uniform over the real states, zero on the padding.
+      // (An edge id that no node lists - possible on the infinite graphs' compact edge sets - keeps all q states.)
+      const int qs = c->edge_src[e] >= 0 ? c->qnode[c->edge_src[e]] : c->q, qd = c->edge_dst[e] >= 0 ? c->qnode[c->edge_dst[e]] : c->q;
+      for (int t = 0; t < L; t++)
+        for (int xd = 0; xd < c->q; xd++)
+          for (int xs = 0; xs < c->q; xs++)
+            slot[(int64_t)t * c->core_stride + xs + (int64_t)c->q * xd] = (xs < qs && xd < qd) ? 1.0 / (qs * qd) : 0.0;
+    }
     HIPCHK(c, hipMemcpy(c->slot_cores(e), slot.data(), sizeof(double) * c->slot_doubles, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->slot_bonds(e), b.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice));
   }
@@ -300,8 +326,12 @@ static int build_tables(mpbp_ctx* c) {
   const int nnz = c->nnz();
   c->pxy_off.assign(nnz, 0); c->pxy_tstride.assign(nnz, 0); c->wmsg_off.assign(nnz, 0);
   c->wbel_off.assign(N, 0); c->init_off.assign(N, 0); c->pyy_base.assign(N, 0);
-  auto PHI = [&](int i, int t, int x) { return c->phi[x + (size_t)q * (t + (size_t)L * i)]; };
-  auto PSI = [&](int e, int t, int xs, int xd) { return c->psi[xs + (size_t)q * (xd + (size_t)q * (t + (size_t)L * e))]; };
+  // heterogeneous nstates: the states x >= qnode[i] of node i are padding - phi and psi are zero there, and so is every
+  // message entry, belief and pair belief; normalisations and free energies are those of the unpadded model
+  auto QS = [&](int e) { return c->edge_src[e] >= 0 ? c->qnode[c->edge_src[e]] : q; };
+  auto QD = [&](int e) { return c->edge_dst[e] >= 0 ? c->qnode[c->edge_dst[e]] : q; };
+  auto PHI = [&](int i, int t, int x) { return x < c->qnode[i] ? c->phi[x + (size_t)q * (t + (size_t)L * i)] : 0.0; };
+  auto PSI = [&](int e, int t, int xs, int xd) { return (xs < QS(e) && xd < QD(e)) ? c->psi[xs + (size_t)q * (xd + (size_t)q * (t + (size_t)L * e))] : 0.0; };
   for (int i = 0; i < N; i++) {
     const NodeFactor& f = c->fac[i];
     const int z = f.deg;
@@ -323,7 +353,7 @@ static int build_tables(mpbp_ctx* c) {
               int64_t cfg = 0, mul = 1, yy = y; int xs[KRON_MAXK + 1];
               for (int k = 0; k < z; k++) { xs[k] = (k == j) ? xj : (int)(yy % q); if (k != j) yy /= q; cfg += mul * xs[k]; mul *= q; }
               for (int x = 0; x < q; x++) {
-                double ps = PHI(i, t, x);
+                double ps = (xj < QD(c->out_edge[p])) ? PHI(i, t, x) : 0.0;        // padding states of the receiving neighbour
                 for (int k = 0; k < z; k++) if (k != j) ps *= PSI(c->out_edge[c->nbr_ptr[i] + k], t, x, xs[k]);
                 for (int xn = 0; xn < q; xn++)
                   w[(size_t)t * q * q * q * nyo + xn + q * (x + q * (xj + (size_t)q * y))] = (t == L - 1) ? ps : ps * GW(t, xn, x, cfg);
@@ -384,7 +414,8 @@ static int build_tables(mpbp_ctx* c) {
             for (int x = 0; x < q; x++)
               for (int xn = 0; xn < q; xn++) {
                 double val;
-                if (t == L - 1 && !c->periodic) val = PHI(i, t, x);
+                if (xj >= QD(eo)) val = 0.0;                                      // padding states of the receiving neighbour
+                else if (t == L - 1 && !c->periodic) val = PHI(i, t, x);
                 else {     // (periodic chains: the last factor couples x^{T+1} to x' = x^1, recursive_bp_factor.jl:94-98)
                   double s = 0.0;
                   for (int y = 0; y < nyz; y++)

@@ -211,10 +211,14 @@ class MPBP:
         assert len(psi) == E
         assert all(len(wi) == T + 1 for wi in w)
         assert all(len(p) == T + 1 for p in phi) and all(len(p) == T + 1 for p in psi)
-        qs = set(int(v) for v in np.atleast_1d(q))
-        if len(qs) != 1:
-            raise MPBPError(-4, "heterogeneous q is not supported on the device path")
-        self.g, self.w, self.q, self.T = g, w, qs.pop(), int(T)
+        # nstates(bp, i) may differ from node to node (src/mpbp.jl:22-26): the device works with q = max_i q_i and treats the
+        # states beyond q_i as padding of exactly zero weight (mpbp_set_node_states, include/mpbp_hip.h)
+        qn = np.atleast_1d(np.asarray(q, dtype=np.int64))
+        qn = np.full(N, int(qn[0])) if qn.size == 1 else qn
+        if qn.size != N or qn.min() < 1:
+            raise MPBPError(-1, f"q must be one positive integer or one per node ({N}), got {q}")
+        self.qnode = np.ascontiguousarray(qn, dtype=np.int32)
+        self.g, self.w, self.q, self.T = g, w, int(qn.max()), int(T)
         for i in range(N):
             # dispatch on the factor type as src/mpbp.jl:191 does (eltype(bp.w[i])): recursive or generic per node
             if not all(isinstance(wt, BPFactor) for wt in w[i]):
@@ -226,12 +230,20 @@ class MPBP:
         self.max_bond = int(max_bond) if max_bond is not None else 16
         self.phi = np.zeros((self.q, T + 1, N))
         self.psi = np.zeros((self.q, self.q, T + 1, E))
+        ends = self._edge_ends(g)
         for i in range(N):
             for t in range(T + 1):
-                self.phi[:, t, i] = phi[i][t]
+                v = np.asarray(phi[i][t], dtype=float)
+                if v.shape != (self.qnode[i],):
+                    raise MPBPError(-1, f"phi[{i}][{t}] must have nstates({i}) = {self.qnode[i]} entries")
+                self.phi[:v.size, t, i] = v
         for e in range(E):
             for t in range(T + 1):
-                self.psi[:, :, t, e] = psi[e][t]
+                m = np.asarray(psi[e][t], dtype=float)
+                if ends is not None and m.shape != (self.qnode[ends[e][0]], self.qnode[ends[e][1]]):
+                    raise MPBPError(-1, f"psi[{e}][{t}] must be nstates(src) x nstates(dst) = {self.qnode[ends[e][0]]} x {self.qnode[ends[e][1]]}")
+                self.psi[:m.shape[0], :m.shape[1], t, e] = m
+        self._ends = ends
         self._check_psis()
         L = _lib.lib()
         self._L = L
@@ -253,10 +265,20 @@ class MPBP:
         h = C.c_void_p()
         _lib.check(L.mpbp_create(C.byref(h), C.byref(d)))
         self._h = h
+        if (self.qnode != self.q).any():
+            _lib.check(L.mpbp_set_node_states(h, _ip(self.qnode)), h)
         self._set_factors()
         _lib.check(L.mpbp_set_phi(h, _dp(np.asfortranarray(self.phi).ravel(order="F"))), h)
         _lib.check(L.mpbp_set_psi(h, _dp(np.asfortranarray(self.psi).ravel(order="F"))), h)
         self.last_stats = None
+
+    @staticmethod
+    def _edge_ends(g):
+        """(src, dst) node of every edge id, or None where the edge set is implicit (InfiniteRegularGraph: one node)."""
+        try:
+            return {int(e): (int(i), int(j)) for (i, j, e) in g.edges()}
+        except Exception:
+            return None
 
     def _check_psis(self):
         """src/mpbp.jl:40-58: ψ on i->j must be the transpose of ψ on j->i."""
@@ -417,8 +439,6 @@ def mpbp_infinite_graph(k, wi, qi, phi_i=None, psi=None, max_bond=None, **kw):
 def mpbp_infinite_bipartite_graph(k, w, qi, phi=None, psi=None, max_bond=None, **kw):
     """src/infinite_graph.jl:93-108"""
     T = len(w[0]) - 1
-    if qi[0] != qi[1]:
-        raise MPBPError(-4, "heterogeneous q is not supported on the device path")
     phi = [[np.ones(qi[i]) for _ in range(T + 1)] for i in range(2)] if phi is None else phi
     psi = [[np.ones((qi[i], qi[1 - i])) for _ in range(T + 1)] for i in range(2)] if psi is None else psi
     # psi is indexed by edge id as in the reference (edge id i = message into node i); the reference
@@ -460,7 +480,7 @@ def beliefs(bp: MPBP):
     buf = np.zeros(out.size)
     _lib.check(bp._L.mpbp_beliefs(bp._h, _dp(buf)), bp._h)
     out = buf.reshape(out.shape, order="F")
-    return [[out[:, t, i].copy() for t in range(bp.T + 1)] for i in range(bp.g.nv())]
+    return [[out[:bp.qnode[i], t, i].copy() for t in range(bp.T + 1)] for i in range(bp.g.nv())]
 
 
 def belief_train(bp: MPBP, i: int):
@@ -567,7 +587,9 @@ def pair_beliefs(bp: MPBP):
     lz = np.zeros(E)
     _lib.check(bp._L.mpbp_pair_beliefs(bp._h, _dp(buf), _dp(lz)), bp._h)
     pb = buf.reshape((q, q, T + 1, E), order="F")
-    b = [[pb[:, :, t, e].copy() for t in range(T + 1)] for e in range(E)]
+    ends = bp._ends
+    qe = (lambda e: (bp.qnode[ends[e][0]], bp.qnode[ends[e][1]])) if ends is not None else (lambda e: (q, q))
+    b = [[pb[:qe(e)[0], :qe(e)[1], t, e].copy() for t in range(T + 1)] for e in range(E)]
     g = bp.g
     if isinstance(g, InfiniteRegularGraph):
         logz = np.array([(1 / (g.k - 1) - 0.5) * lz[0]])

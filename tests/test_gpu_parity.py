@@ -619,6 +619,69 @@ def test_full_size_config1_sampled_node_updates_match_oracle():
         assert abs(f[i] - obp.f[i]) <= 1e-6 * max(1.0, abs(obp.f[i])), (i, f[i], obp.f[i])
 
 
+def _mixed_sis_sirs(A, qs, T, seed):
+    rng = np.random.default_rng(seed)
+    phi = [[rng.random(q) + 0.1 for _ in range(T + 1)] for q in qs]
+    w = [[M.SISFactor(0.3, 0.2)] * (T + 1) if q == 2 else [M.SIRSFactor(0.3, 0.2, 0.1)] * (T + 1) for q in qs]
+    ow = [[OF.SISFactor(0.3, 0.2)] * (T + 1) if q == 2 else [OF.SIRSFactor(0.3, 0.2, 0.1)] * (T + 1) for q in qs]
+    return phi, w, ow
+
+
+def test_heterogeneous_nstates_tree_exact_gpu():
+    """Nodes with different numbers of states (`nstates(bp, i)`, reference src/mpbp.jl:22-26) on the device: SIS nodes (q = 2)
+    and SIRS nodes (q = 3) on one tree, random node observations, no truncation - beliefs, pair beliefs (q_i x q_j blocks)
+    and the partition function against brute-force enumeration at 1e-9, and against the oracle.  The device pads every node to
+    q = 3 states; the padding must carry exactly zero weight (mpbp_set_node_states)."""
+    T = 2                                # 36^3 trajectories to enumerate
+    A = np.array([[0, 1, 1, 0], [1, 0, 0, 1], [1, 0, 0, 0], [0, 1, 0, 0]])
+    qs = [2, 3, 2, 3]
+    phi, w, ow = _mixed_sis_sirs(A, qs, T, 0)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), w, qs, T, phi=phi, max_bond=16)
+    M.iterate(bp, maxiter=6, svd_trunc=M.TruncThresh(0.0), tol=1e-14, shuffle_nodes=False)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), ow, qs, T, phi=phi)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(obp)
+    m = exact_marginals(obp, p)
+    pm = exact_pair_marginals(obp, p)
+    b = M.beliefs(bp)
+    assert [np.array(x).shape for x in b] == [(T + 1, q) for q in qs]
+    assert max(np.abs(np.array(b[i]) - np.array(m[i])).max() for i in range(4)) < 1e-9
+    assert abs(np.exp(-M.bethe_free_energy(bp)) - Z) / Z < 1e-9
+    pb, _ = M.pair_beliefs(bp)
+    for e, (i, j, _) in enumerate(bp.g.edges()):
+        assert np.array(pb[e]).shape == (T + 1, qs[i], qs[j])
+        assert np.abs(np.array(pb[e]) - np.array(pm[e])).max() < 1e-9
+
+
+def test_heterogeneous_nstates_loopy_binding_truncation_matches_oracle_gpu():
+    """The same mixed SIS / SIRS model on a loopy graph with a binding TruncBond(4) and damping: every Jacobi sweep against the
+    oracle (beliefs, per-node free-energy terms, pair beliefs) at the contract's 1e-6.  Bond tables may exceed the oracle's
+    by directions of zero weight where q_i q_j (not the cap) limits a bond, so they are compared as upper bounds."""
+    import ctypes as C
+    T = 5
+    A = nx.to_numpy_array(nx.random_regular_graph(3, 6, seed=3), nodelist=range(6))
+    qs = [2, 3, 3, 2, 3, 2]
+    phi, w, ow = _mixed_sis_sirs(A, qs, T, 1)
+    bp = M.mpbp(M.IndexedBiDiGraph(A), w, qs, T, phi=phi, max_bond=4)
+    obp = O.mpbp(O.IndexedBiDiGraph(A), ow, qs, T, phi=phi)
+    for s in range(4):
+        M.iterate(bp, maxiter=1, svd_trunc=M.TruncBond(4), tol=0.0, damp=0.2)
+        O.iterate(obp, maxiter=1, svd_trunc=OT.TruncBond(4), tol=0.0, shuffle_nodes=False, jacobi=True, damp=0.2)
+        b, ob = M.beliefs(bp), O.beliefs(obp)
+        for i in range(6):
+            np.testing.assert_allclose(np.array(b[i]), np.array(ob[i]), rtol=1e-6, atol=1e-12)
+        f = np.zeros(6)
+        bp._L.mpbp_free_energy(bp._h, f.ctypes.data_as(C.POINTER(C.c_double)))
+        np.testing.assert_allclose(f, np.array(obp.f), rtol=1e-6, atol=1e-9)
+    pb, lz = M.pair_beliefs(bp)
+    opb, olz = O.pair_beliefs(obp)
+    for e in range(bp.g.ne()):
+        np.testing.assert_allclose(np.array(pb[e]), np.array(opb[e]), rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(lz, olz, rtol=1e-6, atol=1e-9)
+    assert bp.bonds().max() == 4
+    assert (bp.bonds() >= np.array([m.bonds for m in obp.mu])).all()
+
+
 def _check_node_properties(bp, nodes, Mb, st):
     assert st.nan_flag == 0 and st.capacity_flag == 0 and st.jacobi_not_converged == 0
     b = np.array(M.beliefs(bp))[nodes]

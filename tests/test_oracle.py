@@ -404,3 +404,28 @@ def test_generic_factor_tables_of_the_host_mirror_match_the_functor():
     assert all(isinstance(wi[0], M.GenericGlauberFactor) for wi in M.glauber_factors(J != 0, J, np.zeros(3), 1.0, 2))
     J2 = np.where(J != 0, 0.5, 0.0)
     assert all(isinstance(wi[0], M.HomogeneousGlauberFactor) for wi in M.glauber_factors(J2 != 0, J2, np.zeros(3), 1.0, 2))
+
+
+def test_oracle_heterogeneous_nstates_tree_is_exact():
+    """`nstates(bp, i)` differing from node to node (reference src/mpbp.jl:22-26; messages of edge i->j are MPEM2s over q_i x q_j,
+    src/recursive_bp_factor.jl:155): SIS nodes (q = 2) and SIRS nodes (q = 3) on one tree with random node observations - BP
+    without truncation against brute-force enumeration.  Pins the oracle for the device's padded-state implementation
+    (mpbp_set_node_states)."""
+    from oracle import factors as OF, mpbp as O
+    from oracle.exact import exact_marginals, exact_prob
+    from oracle.tensor_trains import TruncThresh
+    T = 2                                # 36^3 trajectories to enumerate
+    A = np.array([[0, 1, 1, 0], [1, 0, 0, 1], [1, 0, 0, 0], [0, 1, 0, 0]])
+    qs = [2, 3, 2, 3]
+    w = [[OF.SISFactor(0.3, 0.2)] * (T + 1) if q == 2 else [OF.SIRSFactor(0.3, 0.2, 0.1)] * (T + 1) for q in qs]
+    rng = np.random.default_rng(0)
+    phi = [[rng.random(q) + 0.1 for _ in range(T + 1)] for q in qs]
+    bp = O.mpbp(O.IndexedBiDiGraph(A), w, qs, T, phi=phi)
+    O.iterate(bp, maxiter=6, svd_trunc=TruncThresh(0.0), tol=1e-14, shuffle_nodes=False)
+    with np.errstate(divide="ignore"):
+        p, Z = exact_prob(bp)
+    m = exact_marginals(bp, p)
+    b = O.beliefs(bp)
+    assert [np.array(x).shape for x in b] == [(T + 1, q) for q in qs]
+    assert max(np.abs(np.array(b[i]) - np.array(m[i])).max() for i in range(4)) < 1e-12
+    assert abs(np.exp(-O.bethe_free_energy(bp)) - Z) / Z < 1e-12
