@@ -594,6 +594,17 @@ __device__ __forceinline__ void touch_tile(const gdbl* Y, long ld, const int (&b
   }
 #endif
 }
+#ifdef CQ_NO_LDS
+// probe operand values: CQ_NO_LDS=1 a low-activity constant (1 + k 1e-9: mostly zero mantissa bits), CQ_NO_LDS=2 a full random mantissa
+__device__ __forceinline__ double CQ_NO_LDS_VALUE(unsigned k) {
+#if CQ_NO_LDS == 2
+  unsigned long long h = (k + 1) * 0x9E3779B97F4A7C15ULL; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+  return __longlong_as_double((long long)((h >> 12) | 0x3FF0000000000000ULL)) - 1.5;
+#else
+  return 1.0 + 1e-9 * (double)k;
+#endif
+}
+#endif
 #ifdef CQ_UPROF
 __device__ unsigned long long cq_uprof[8];
 #define CQ_UT(slot) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&cq_uprof[slot], t1_ - cq_ut0); cq_ut0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -629,6 +640,11 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
       cE[s] = lo + hi; cO[s] = lo - hi;
     }
   }
+#ifdef CQ_NO_LDS
+  double cst[16];                      // the stand-in operands: sixteen registers, filled once
+#pragma unroll
+  for (int k = 0; k < 16; k++) cst[k] = CQ_NO_LDS_VALUE(threadIdx.x * 16 + k);
+#endif
   CQ_UT_DECL;
 #ifdef CQ_UPROF
   { double sink = 0; for (int rb = 0; rb < 16; rb++) sink += C[rb][0] + C[rb][3]; if (sink == 1.2345e301) cp[0] = sink; }   // wait for the tile here
@@ -649,14 +665,22 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
     for (int e = 0; e < 4; e++) { Vlo[e] = V + ((p & 1) ? aO[e] : aE[e]); Vhi[e] = Vlo[e] + 8192; }
     double a[4], an[4];
 #pragma unroll
+#ifdef CQ_NO_LDS          // probe builds: the reflector operands are constants in registers (no LDS traffic at all)
+    for (int e = 0; e < 4; e++) a[e] = cst[(e + 4 * p) & 15];
+#else
     for (int e = 0; e < 4; e++) a[e] = Vlo[e][16 * p];                       // row group 0 is never skipped
+#endif
 #pragma unroll
     for (int rb = 0; rb < 16; rb++) {
       if (tree_skip(TREE, rb, p)) continue;
       const int nx = tree_next(TREE, rb, p);
       if (nx < 16) {
 #pragma unroll
+#ifdef CQ_NO_LDS
+        for (int e = 0; e < 4; e++) an[e] = a[e];
+#else
         for (int e = 0; e < 4; e++) an[e] = (nx < 8) ? Vlo[e][16 * p + 1024 * nx] : Vhi[e][16 * p + 1024 * (nx - 8)];
+#endif
       }
 #pragma unroll
       for (int e = 0; e < 4; e++) acc = mfma(a[e], C[rb][e], acc);
@@ -704,7 +728,11 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
     for (int p = 0; p < 4; p++) {
       if (tree_skip(TREE, rb, p)) continue;
 #pragma unroll
+#ifdef CQ_NO_LDS
+      for (int s = 0; s < 4; s++) dst[p][s] = cst[(4 * p + s + 5 * rb) & 15];
+#else
       for (int s = 0; s < 4; s++) dst[p][s] = cb[p & 1][rb >> 3][s][16 * p + 1024 * (rb & 7)];
+#endif
     }
   };
   fetch(0, a);
@@ -745,7 +773,12 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
 // at 2.4 GHz, 20.8 us with half the CUs busy; the shader clock under this load is 2.26 GHz (s_memtime against s_memrealtime,
 // -DCQ_UPROF), so a wave spends ~84 cycles per 64-cycle MFMA whatever stands between them; (iv) the next row group's LDS
 // reads forced right behind the first MFMA of a group (sched_group_barrier; the compiler issues them after the last one, 64
-// cycles before their use): no change; (v) eight-wave workgroups (two waves per SIMD, 256 registers, spills): 30-33 TFLOP/s.)
+// cycles before their use): same wait counts as hand analysis (lgkmcnt 6 / 5 / 4), no change; (v) eight-wave workgroups (two
+// waves per SIMD, 256 registers, spills): 30-33 TFLOP/s; (vi) -DCQ_NO_GLOBAL -DCQ_NO_LDS: the same MFMA stream with its A
+// operands in registers - no LDS, no global traffic, no waits.  With SIXTEEN operand registers cycling it reaches 49 (random
+// mantissas) - 52 (1 + k 1e-9) TFLOP/s; with FOUR loop-invariant ones 74 - 76 (the data-sheet peak).  So the ceiling of this
+// stream on this part is set by the variety of the MFMA's source registers (operand fetch from the register file), not by
+// LDS, memory, waits or the clock, and the shipped kernel (40 with memory, 45 without) runs at 80 - 90 % of it.)
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int level, int slot, int node, int tg, int tpg,
