@@ -543,18 +543,16 @@ __device__ __forceinline__ void fac2_kernel_body(const v2::QrProb* probs, int64_
   if (level == 0) fac2_body<false>(Pr, ws_off, jb, slot0 + blockIdx.x, base, cnt, la, lds);
   else fac2_body<true>(Pr, ws_off, jb, slot0 + blockIdx.x, base, cnt, la, lds);
 }
-// Two builds of the same body: k_cq_fac2 with the whole register file of a SIMD for its wave (256 + ~170 registers, no scratch:
-// the fastest single node, 81 us - taken when the launch has at most one node per CU), k_cq_fac2x2 at two waves per SIMD
-// (256 registers, the spills sit outside the column steps; a node takes 90 us but two share a CU: the many-node launches).
+// One 256-thread workgroup per node and per CU: a lone wave per SIMD with the whole register file (256 + ~240 registers, no
+// scratch).  (Round 3 also built the body at two waves per SIMD - `k_cq_fac2x2`, 256 registers, 1072 spills, 459 scratch loads
+// and 334 stores of them inside the column steps - for launches with more nodes than CUs; with the column steps straight-line
+// it no longer bought anything - 63.5 against 63.8 ms at 7200 x 900 x 128 - and was removed in round 4.)
 __global__ void __launch_bounds__(256) k_cq_fac2(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int la) {
   extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
   fac2_kernel_body(probs, ws_off, jb, level, slot0, la, (ldbl*)cq_lds_raw);
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_cq_fac2x2(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int la) {
-  extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
-  fac2_kernel_body(probs, ws_off, jb, level, slot0, la, (ldbl*)cq_lds_raw);
-}
 
+// ------------------------------------------------------------------------------------------------------------------
 // One trailing tile (256 node rows in four segments x 16 columns at col0) against the node's LDS image.
 // nrb: valid 16-row groups (a prefix of the node's rows).
 // TREE: the node is a stack of four triangles - sub-panel p of the image is zero in the row groups (rb & 3) > p of every

@@ -104,10 +104,8 @@ static void set_func_attrs_once() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = -1;
   if (dev >= 0) { std::lock_guard<std::mutex> lk(g_dev[dev].mu); if (g_dev[dev].attrs) return; g_dev[dev].attrs = true; }
   hipFuncSetAttribute((const void*)v2::k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2::fpanel_lds_bytes(3));
-  hipFuncSetAttribute((const void*)cq::k_cq_upd<512>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
   hipFuncSetAttribute((const void*)cq::k_cq_upd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
   hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
-  hipFuncSetAttribute((const void*)cq::k_cq_fac2x2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
   hipFuncSetAttribute((const void*)cq::k_cq_updfac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
   hipFuncSetAttribute((const void*)v2::k_jac_block, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 }
@@ -222,13 +220,12 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       // groups with the fewest (rounds over the CUs) x (time of a workgroup: ~12 us of image load + 6.2 us per tile, measured
       // with the chip full) - it decides how the last round is filled
       static const double img_us = [] { const char* e = getenv("MPBP_CQ_IMG_US"); return e ? atof(e) : 12.0; }();
-      static const int upd_nt = [] { const char* e = getenv("MPBP_CQ_NT"); return (e && atoi(e) == 512) ? 512 : 256; }();
       auto tile_groups = [&](int ntl, int n, int& tpg, int& nthr) {
         const int64_t tiles = (int64_t)ntl * n * P;
-        // four-wave workgroups always: the eight-wave build (two waves per SIMD at 256 registers) spills and measured
-        // 30-33 against 38-40 TFLOP/s on every tile-group size (tools/probes/cq_upd_probe.hip); it only remains for MPBP_CQ_NT=512
-        tpg = 8; nthr = upd_nt;
-        if (tiles <= 4 * ncu) { tpg = 4; nthr = 256; return; }
+        // four-wave workgroups always: the eight-wave build of round 3 (two waves per SIMD at 256 registers, 155 - 495 spills)
+        // measured 30-33 against 38-40 TFLOP/s on every tile-group size (profiles/r04_cq_upd_probe.txt) and was removed
+        tpg = 8; nthr = 256;
+        if (tiles <= 4 * ncu) { tpg = 4; return; }
         double best = 1e30;
         for (int g = 1; g <= (ntl + 7) / 8; g++) {
           const int t = (ntl + g - 1) / g;
@@ -243,13 +240,14 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
         int nl[12], nlev = 0;
         for (int n = (rows32_max - jb + 255) / 256; nlev < 12; n = (n + 3) / 4) { nl[nlev++] = n; if (n == 1) break; }
         int slot = 0;
-        // more nodes than CUs: the two-per-CU build of the factor kernel
-        if ((int64_t)nl[0] * P > ncu) hipLaunchKernelGGL(cq::k_cq_fac2x2, dim3(nl[0], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, 0, 0, 0);
-        else hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[0], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, 0, 0, 0);
+        // (Round 3 had a second build of this kernel at two waves per SIMD for launches with more nodes than CUs.  Since the
+        //  column steps are straight-line code the one-per-CU build is as fast per CU - 7200 x 900 x 128: 63.5 against 63.8 ms,
+        //  21600 x 900 x 16: 28.1 / 28.2, 6400 x 1600 x 16: 22.5 / 22.4 - and the other one carried 1072 spills: removed.)
+        hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[0], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, 0, 0, 0);
         for (int level = 0; level < nlev; level++) {
           const int n = nl[level];
           const bool more = level + 1 < nlev;
-          int tpg = 8, nthr = 512;
+          int tpg = 8, nthr = 256;
           if (ntl > 0) tile_groups(ntl, n, tpg, nthr);
           const int ntg = ntl > 0 ? (ntl + tpg - 1) / tpg : 0;
           if (ntl > 0 && more && !no_fuse) {
@@ -258,12 +256,10 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
                                tpg, slot + n, nl[level + 1]);
           } else {
             if (ntl > 0) {
-              if (nthr == 256) hipLaunchKernelGGL(cq::k_cq_upd<256>, dim3(ntg, n, P), dim3(256), cq::UPD_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level, slot, tpg, 0);
-              else hipLaunchKernelGGL(cq::k_cq_upd<512>, dim3(ntg, n, P), dim3(512), cq::UPD_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level, slot, tpg, 0);
+              hipLaunchKernelGGL(cq::k_cq_upd<256>, dim3(ntg, n, P), dim3(256), cq::UPD_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level, slot, tpg, 0);
             }
             if (more) {
-              if ((int64_t)nl[level + 1] * P > ncu) hipLaunchKernelGGL(cq::k_cq_fac2x2, dim3(nl[level + 1], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level + 1, slot + n, 0);
-              else hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[level + 1], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level + 1, slot + n, 0);
+              hipLaunchKernelGGL(cq::k_cq_fac2, dim3(nl[level + 1], P), dim3(256), cq::FAC_LDS_DOUBLES * 8, st, d_probs, ws_off, jb, level + 1, slot + n, 0);
             }
           }
           slot += n;

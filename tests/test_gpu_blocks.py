@@ -137,8 +137,8 @@ def test_qr_batched_tall(rows, cols):
 
 
 def test_qr_batched_tree_many_nodes_two_per_cu_and_ragged_tail():
-    """The communication-avoiding form (csrc/cq_kernels.h) with more level-0 nodes than CUs: the two-per-CU build of the node
-    factorisation (k_cq_fac2x2), upper levels inside the fused update + factorisation launches, a last node of 32 rows
+    """The communication-avoiding form (csrc/cq_kernels.h) with more level-0 nodes than CUs (several rounds of node
+    factorisations per launch), upper levels inside the fused update + factorisation launches, a last node of 32 rows
     (rows = 2112 + 32) and rank-deficient / badly scaled columns; every problem against LAPACK."""
     rng = np.random.default_rng(24)
     for (r, c, nprob) in [(4128, 192, 40), (2144, 320, 36)]:

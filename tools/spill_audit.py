@@ -76,7 +76,7 @@ def main():
         desc = ", ".join(f"{count(body[s:e + 1], 'scratch_load')}/{count(body[s:e + 1], 'v_mfma')}" for s, e in inner[:14])
         print(f"{d:100s} {len(body):6d} {ld:10d} {st:5d} {mf:5d}   {desc}")
     lines = asm("v2_engine.hip")
-    print("\n== csrc/v2_engine.hip: node factorisation of the batched QR (cq::k_cq_fac2 one workgroup per CU, cq::k_cq_fac2x2 two per CU):")
+    print("\n== csrc/v2_engine.hip: node factorisation of the batched QR (cq::k_cq_fac2, one workgroup per CU; the fused update + factorisation launch k_cq_updfac) and its update kernels:")
     print("   straight-line code between workgroup barriers; a COLUMN-STEP segment = no MFMA and at least eight DPP row broadcasts")
     for n, body in functions(lines):
         d = demangle(n)
