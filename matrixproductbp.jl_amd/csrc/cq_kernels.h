@@ -639,9 +639,12 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
     }
   }
 #ifdef CQ_NO_LDS
-  double cst[16];                      // the stand-in operands: sixteen registers, filled once
+#ifndef CQ_NCST
+#define CQ_NCST 16
+#endif
+  double cst[CQ_NCST];                 // the stand-in operands: CQ_NCST registers (a power of two), filled once
 #pragma unroll
-  for (int k = 0; k < 16; k++) cst[k] = CQ_NO_LDS_VALUE(threadIdx.x * 16 + k);
+  for (int k = 0; k < CQ_NCST; k++) cst[k] = CQ_NO_LDS_VALUE(threadIdx.x * 16 + k);
 #endif
   CQ_UT_DECL;
 #ifdef CQ_UPROF
@@ -664,7 +667,7 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
     double a[4], an[4];
 #pragma unroll
 #ifdef CQ_NO_LDS          // probe builds: the reflector operands are constants in registers (no LDS traffic at all)
-    for (int e = 0; e < 4; e++) a[e] = cst[(e + 4 * p) & 15];
+    for (int e = 0; e < 4; e++) a[e] = cst[(e + 4 * p) & (CQ_NCST - 1)];
 #else
     for (int e = 0; e < 4; e++) a[e] = Vlo[e][16 * p];                       // row group 0 is never skipped
 #endif
@@ -727,7 +730,7 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
       if (tree_skip(TREE, rb, p)) continue;
 #pragma unroll
 #ifdef CQ_NO_LDS
-      for (int s = 0; s < 4; s++) dst[p][s] = cst[(4 * p + s + 5 * rb) & 15];
+      for (int s = 0; s < 4; s++) dst[p][s] = cst[(4 * p + s + 5 * rb) & (CQ_NCST - 1)];
 #else
       for (int s = 0; s < 4; s++) dst[p][s] = cb[p & 1][rb >> 3][s][16 * p + 1024 * (rb & 7)];
 #endif
