@@ -779,7 +779,9 @@ __device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)
 // operands in registers - no LDS, no global traffic, no waits.  With SIXTEEN operand registers cycling it reaches 49 (random
 // mantissas) - 52 (1 + k 1e-9) TFLOP/s; with FOUR loop-invariant ones 74 - 76 (the data-sheet peak).  So the ceiling of this
 // stream on this part is set by the variety of the MFMA's source registers (operand fetch from the register file), not by
-// LDS, memory, waits or the clock, and the shipped kernel (40 with memory, 45 without) runs at 80 - 90 % of it.)
+// LDS, memory, waits or the clock, and the shipped kernel (40 with memory, 45 without) runs at 80 - 90 % of it.  (By number of
+// distinct A registers: 2 or 4 -> 73.6, 8 -> 63.8, 16 or 32 -> 49.5 TFLOP/s.  Fewer LDS-FED registers do not help: phase C with
+// its operands fetched one sub-panel ahead - 8 instead of 32 registers - 40.2 against 39.5 TFLOP/s.))
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int level, int slot, int node, int tg, int tpg,
