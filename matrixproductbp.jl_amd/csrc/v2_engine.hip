@@ -875,18 +875,25 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
     // ... and only for a handful of problems: with many, one workgroup per problem keeps every CU busy and the 659
     // launches per sweep only add latency (configs[2] shard: 498 s with the grid form on every level, 327 s without)
     const int jac_grid_maxp = [] { const char* e = getenv("MPBP_JACOBI_GRID_MAXP"); return e ? atoi(e) : 4; }();
-    // MPBP_JACOBI_FORM = wg (one workgroup per problem) | grid (one launch per round) | block (two-level, LDS-resident block
-    // pairs); default: wg, and grid for factors of >= 384 columns in batches of <= 4 problems.  The block form was built for
-    // the round-3 review (item 6) and measured on one box each (profiles/r04_jacobi_forms.txt): configs[3] sweep 95.9 against
-    // 95.7 s, configs[4] iteration 26.0 / 27.0 against 24.8 / 26.5 s, a configs[2] block 351 s against 220 s before it got
-    // the deflation of wg::jacobi_rsv.  What makes the one-workgroup form fast is that deflation - on BP factors two thirds
-    // of the columns are numerically null after two sweeps - not the memory level its columns live in; the block form meets
-    // every pair of a block nblk - 1 times per sweep and pays a launch per block round.  It stays selectable and tested.
+    // Form of the Jacobi (MPBP_JACOBI_FORM = wg | grid | block forces one):
+    //   wg     one workgroup per problem (wg::jacobi_rsv inside k_svd_trunc): the default for factors below 320 columns and for
+    //          batches of more than 32 problems - with a CU per problem the chip is full, and no pair is met twice per sweep;
+    //   block  two-level (v2::k_jac_block + k_jac_deflate): block pairs LDS resident, blocks / 2 workgroups per problem, one
+    //          launch per round of the block tournament: the default for factors of >= 320 columns in batches of <= 32
+    //          problems - the hub levels of configs[2], where one CU per problem rotates 400 ... 780-column factors out of HBM
+    //          while the rest of the chip idles.  Round 4, one configs[2] node block on one box (profiles/r04_jacobi_forms.txt):
+    //          Jacobi + truncation in the batches of 2 - 4 problems 7.5 -> 2.4 s (the grid form's regime in round 3), of 5 - 32
+    //          problems 9.8 -> 6.0 s, sweep 219.8 -> 212.8 s.  Below 320 columns it does not pay: configs[3] (160 columns) 89.1
+    //          against 91.7 s, configs[4] (256 columns, <= 3 problems) 26.0 / 27.0 against 24.8 / 26.5 s per iteration.  It NEEDS
+    //          the deflation of wg::jacobi_rsv (BP factors: numerical rank ~2/3, most columns null after two sweeps): without
+    //          it the same configs[2] block took 351 s.
+    //   grid   one launch per tournament round over the grid (k_jac_round, no deflation; round 3's form for >= 384 columns and
+    //          <= 4 problems): superseded by block, kept selectable and tested.
     const int jac_form = [] { const char* e = getenv("MPBP_JACOBI_FORM"); return !e ? 0 : (!strcmp(e, "wg") ? 1 : (!strcmp(e, "grid") ? 2 : (!strcmp(e, "block") ? 3 : 0))); }();
-    const int jac_block_min = [] { const char* e = getenv("MPBP_JACOBI_BLOCK_MIN"); return e ? atoi(e) : 96; }();
+    const int jac_block_min = [] { const char* e = getenv("MPBP_JACOBI_BLOCK_MIN"); return e ? atoi(e) : 320; }();
     // ... and only while one workgroup per problem leaves most of the chip idle: with a CU per problem for a whole batch the
     // one-workgroup form is at full occupancy and does fewer rotations (no pair is met twice per sweep)
-    const int jac_block_maxp = [] { const char* e = getenv("MPBP_JACOBI_BLOCK_MAXP"); return e ? atoi(e) : 64; }();
+    const int jac_block_maxp = [] { const char* e = getenv("MPBP_JACOBI_BLOCK_MAXP"); return e ? atoi(e) : 32; }();
     const size_t svd_lds = sizeof(double) * (32 + (size_t)rrm + (rrm + 1) / 2 + 4);
     HIPCHK(c, hipFuncSetAttribute((const void*)v2::k_svd_trunc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)svd_lds));
     for (int t = 0; t < L; t++) {
@@ -932,8 +939,8 @@ int v2_gauge_sweep(mpbp_ctx* c, EngProb* probs, int n, const int32_t* hb, const 
       // factors of a hundred columns and more: the two-level (block) Jacobi - block pairs LDS resident, blocks / 2
       // workgroups per problem, one launch per round of the block tournament (v2::k_jac_block)
       int jnb = 0;
-      if (jac_form == 3 && k2t >= jac_block_min && rrt <= 1024 && P <= jac_block_maxp) jnb = jac_block_nb(rrt, k2t);
-      const bool jgrid = !jnb && jac_form != 1 && rrt <= 1024 && k2t >= jac_grid_min && P <= jac_grid_maxp;
+      if ((jac_form == 0 || jac_form == 3) && k2t >= (jac_form == 3 ? 96 : jac_block_min) && rrt <= 1024 && P <= jac_block_maxp) jnb = jac_block_nb(rrt, k2t);
+      const bool jgrid = !jnb && jac_form == 2 && rrt <= 1024 && k2t >= jac_grid_min && P <= jac_grid_maxp;
       if (jnb) {
         hipLaunchKernelGGL(v2::k_svd_trunc, dim3(P), dim3(512), svd_lds, st, dsvt, c->d_stats, 1);
         const size_t jlds = sizeof(double) * ((size_t)(rrt | 1) * 2 * jnb + 32);
