@@ -709,7 +709,7 @@ def test_full_size_baseline_configs2_glauber_er_properties():
     saturated incoming bonds, of nodes of degree 0 .. 6 (product bond 900, nstates = l+1 growing along the cavity:
     Y_t up to 900 x 7 x 2 = 12600 rows), through the batched gauge sweep.  Size-independent properties.
     (The two sweeps that bring the whole graph to the cap take ~90 s on one GPU and are not repeated here; a saturated sweep
-    of one of the eight node blocks takes 215 - 227 s, profiles/r04_config2_all_shards.txt; the degree-9 hub is pinned by the
+    of one of the eight node blocks takes 211 - 228 s, profiles/r04_config2_all_shards.txt; the degree-9 hub is pinned by the
     fixture tests/golden/hub_glauber9.npz.)"""
     N, T, Mb = 2048, 100, 30
     G = nx.gnp_random_graph(N, 4 / (N - 1), seed=0)
@@ -735,7 +735,7 @@ def test_full_size_baseline_configs3_karate_properties():
     """BASELINE configs[3] at its stated dimensions (SIS lambda=0.1 rho=0.05 on notebooks/karate.txt, node 0 infected at
     t=0, T=200, TruncBond(40)): one update at saturated incoming bonds of nodes of degree 1 .. 5 (products of bond
     40 x 40 = 1600, Y_t = 6400 x 1600).  Full sweeps over the whole graph including the two hubs (cavity chains of 46 /
-    49 products; 94 / 124 s for the third / fourth whole-graph sweep) are recorded in
+    49 products; 91 / 122 s for the third / fourth whole-graph sweep) are recorded in
     profiles/r04_config3_karate_T200_d40_full_sweeps.log; the degree-17 hub is pinned by tests/golden/hub_karate17.npz."""
     A = _karate()
     N, T, Mb = 34, 200, 40
