@@ -33,6 +33,7 @@
 //   operand images of the 16-column triangular factors T_p (p = 0..3) and the cross Grams S_pr (r < p):
 //     Timg[p][s][lane (g, c)] = T_p[4g + s][sigma(c)],  Simg[p,r][s][lane] = -S_pr[sigma(c)][4g + s]
 #pragma once
+#include <type_traits>
 
 namespace cq {
 using namespace wgc;
@@ -558,22 +559,13 @@ __global__ void __launch_bounds__(256) k_cq_fac2(const v2::QrProb* probs, int64_
 // TREE: the node is a stack of four triangles - sub-panel p of the image is zero in the row groups (rb & 3) > p of every
 // segment, those products are skipped (5/8 of the MFMAs remain).
 constexpr bool tree_skip(bool tree, int rb, int p) { return tree && (rb & 3) > p; }
-constexpr int tree_next(bool tree, int rb, int p) {          // the next row group after rb that sub-panel p touches (16: none)
-  for (int r = rb + 1; r < 16; r++) if (!tree_skip(tree, r, p)) return r;
-  return 16;
-}
-__device__ __forceinline__ void load_tile(const gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16]) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const gdbl* cp = Y + (long)(col0 + c) * ld + 4 * g;
-#pragma unroll
-  for (int rb = 0; rb < 16; rb++) {
-    C[rb] = d4{0, 0, 0, 0};
-    if (rb < nrb) C[rb] = __builtin_nontemporal_load(reinterpret_cast<const gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
-  }
+constexpr int pair_next(bool tree, int rb, int p) {           // the next (row group, sub-panel) = 4 rb + p after this one (64: none)
+  for (int k = 4 * rb + p + 1; k < 64; k++) if (!tree_skip(tree, k >> 2, k & 3)) return k;
+  return 64;
 }
 // Touches the tile at column col_next: one 4-byte load per 128-byte line of the wave's 16 column segments (row group
-// (lane >> 4) + 4 k, column lane & 15), so that the real load one tile later hits the L2 instead of waiting for HBM.  A wave
-// of the update has no second wave on its SIMD to switch to, and a second tile buffer in registers spills (k_cq_upd).  The
+// (lane >> 4) + 4 k, column lane & 15), so that the real load one tile later finds it in a cache instead of waiting for HBM.  A wave
+// of the update has no second wave on its SIMD to switch to, and a second tile buffer in registers gains nothing (upd_body).  The
 // loads go straight to an LDS landing zone nobody reads (global_load_lds_dword: no destination register, so nothing the
 // register allocator does can be hit by the late write) and are issued AFTER the wave has waited for its own tile, from
 // inline assembly the compiler's wait-count model does not see: no instruction waits for them, a later wait at most over-waits.
@@ -592,200 +584,201 @@ __device__ __forceinline__ void touch_tile(const gdbl* Y, long ld, const int (&b
   }
 #endif
 }
-#ifdef CQ_NO_LDS
-// probe operand values: CQ_NO_LDS=1 a low-activity constant (1 + k 1e-9: mostly zero mantissa bits), CQ_NO_LDS=2 a full random mantissa
-__device__ __forceinline__ double CQ_NO_LDS_VALUE(unsigned k) {
-#if CQ_NO_LDS == 2
-  unsigned long long h = (k + 1) * 0x9E3779B97F4A7C15ULL; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
-  return __longlong_as_double((long long)((h >> 12) | 0x3FF0000000000000ULL)) - 1.5;
+#ifdef CQ_TRACE
+// probe builds: per wave and tile, the shader clock at [0] tile requested, [1] tile arrived, [2] end of phase A, [3] of B, [4] of C
+__device__ unsigned long long* cq_trace_buf;
+#define CQ_TR(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+  if ((threadIdx.x & 63) == 0) cq_trace_buf[((long)(blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64 * 5 + cq_tr_tile * 5 + (k)] = t_; \
+  __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ int cq_tr_dummy;
 #else
-  return 1.0 + 1e-9 * (double)k;
+#define CQ_TR(k) do {} while (0)
 #endif
+#ifdef CQ_TRACE
+#define CQ_TR0(tile) do { const int cq_tr_tile = (tile); CQ_TR(0); } while (0)
+#else
+#define CQ_TR0(tile) do {} while (0)
+#endif
+// ------------------------------------------------------------------------------------------------------------------
+// compute_tile: one trailing tile (256 node rows in four segments x 16 columns) against the node's LDS image.
+//
+// Written (round 4) around what tools/probes/mfma_operand_probe.hip measured on gfx950 (profiles/r04_mfma_operand_probe.txt):
+//  * v_mfma_f64_16x16x4_f64 issues every 64 cycles from ONE wave per SIMD whatever the operands are: a dependent chain on one
+//    accumulator, 2 - 16 accumulators taking turns, 1 - 16 distinct A and B source registers - 77.4 - 77.9 TFLOP/s chip-wide in
+//    every case (the data-sheet 78.6).  (An earlier note in this file blamed "the variety of the MFMA's source registers" for
+//    the 49 TFLOP/s ceiling of this kernel's instruction stream: wrong - the stand-in builds with few operand registers had
+//    three of the four sub-panel products of phase A merged by the compiler and executed 65 % of the MFMAs.)
+//  * the fp64 MFMA runs on the SIMD's own double-precision lanes (matrix and vector fp64 peak are the same number), and EVERY
+//    VALU instruction of ANY wave of that SIMD is time taken from the MFMA stream: one v_add_u32 behind each MFMA of a chain
+//    costs 11.8 cycles, each further one 4 - 5 (8 per MFMA: 104.6 instead of 64 cycles), a v_accvgpr_write + read pair 19; a
+//    second wave on the SIMD does not hide them (2 waves, 1 VALU each per MFMA: 69.9 cycles per MFMA);
+//  * one ds_read_b64 behind every MFMA is free, two cost 9.5 cycles.
+// The round-3 tile code had 1.4 VALU instructions per MFMA (LDS addresses with > 16-bit offsets re-added before every read:
+// 708 v_add_u32 per 1824 MFMAs; every tile load and store moved through VGPR <-> AGPR copies: 1432; 130 address adds) and its
+// phases A / C took 1.5 - 2.2 x their MFMA issue time.  Here the MFMA stream has none:
+//  * every LDS address is one of 16 registers per phase (set up at the start of the phase from two lane constants the
+//    optimiser cannot see through - else it hoists them out of the tile loop and spills them, or folds the 64 KB half into
+//    the immediate and re-adds it) + a 16-bit immediate;
+//  * global addresses are a uniform segment pointer (scalar registers) + ONE per-lane byte offset + an immediate;
+//  * the LDS operands ping-pong between two register sets by a compile-time index, one read of the next group in front of
+//    every MFMA of this one (no copies, one ds_read per MFMA);
+//  * the sign of phase C rides on the MFMA's negate-A bit; a full node's tile is loaded without the zero fill;
+//  * nothing is kept in a VGPR across phases that a scratch reload would have to bring back (a scratch load waits for the
+//    outstanding tile loads as well).
+// Per tile and wave, shader cycles, 256 tiles x 64 nodes (tools/probes/cq_upd_probe.hip -DCQ_TRACE; MFMA issue 16384 / 2560 /
+// 16384): phase A 17.1 K, B 3.7 K, C 18.8 K (20.2 K with the touches in it) - 90 % of the issue rate - and the tile itself:
+// 13.9 K cycles from request to arrival untouched, 8.8 K touched a tile ahead, 3.9 K touched half a tile ahead (shipped).
+// What is left is that wait and the image load of a workgroup (~36 K cycles): 43.8 against 40 TFLOP/s in the probe,
+// -3.5 % on the factorisations (7200 x 900 x 128: 64.3 -> 62.2 ms; 5400 x 900 x 256: 94.4 -> 91.9; 16384 x 4096: 27.7 -> 27.1;
+// profiles/r04_qrbench3.txt).  Tried on top of it and measured (same probe, profiles/r04_cq_upd_probe.txt):
+//  * two waves per SIMD (512 threads, <= 256 registers, tiles handed out through an LDS counter): 43 - 46.6 TFLOP/s at 256
+//    workgroups and 49.9 with four rounds of workgroups (256 threads: 40.2), 58.6 without global traffic - but the fused
+//    update + factor launch needs the 256-thread shape (the factor nodes use 496 registers), and unfused the factorisations
+//    lose more than the update gains except at >= 128 problems (7200 x 900 x 128: 61.0 against 62.0 ms);
+//  * two tile buffers in the 512 registers of a lone wave, the next tile requested as soon as the current one has arrived:
+//    396 registers, no spill, but the compiler's wait in front of the first MFMA of every tile is vmcnt(0) - it waits for the
+//    tile just requested as well; with straight-line loop bodies the count is right (vmcnt(32)) but the allocator keeps both
+//    buffers in the architectural half, spills addresses, and every scratch reload is a vmcnt(0) again; pinned into the
+//    accumulation half by "+a" constraints it copies them back and forth (1312 v_accvgpr_*): no gain in any form;
+//  * the next tile's row groups requested inside phase C, each behind the store that frees its registers: 239 spills.
+// uniform base + this lane's 32-bit byte offset + a constant: the shape the compiler turns into `global_* v_off, s[base:base+1] offset:imm`
+__device__ __forceinline__ gd4* lane_ptr(gdbl* base, unsigned lane_bytes, int doubles) {
+  typedef __attribute__((address_space(1))) char gchar;
+  return reinterpret_cast<gd4*>(reinterpret_cast<gchar*>(base) + lane_bytes + 8 * doubles);
 }
-#endif
-#ifdef CQ_UPROF
-__device__ unsigned long long cq_uprof[8];
-#define CQ_UT(slot) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&cq_uprof[slot], t1_ - cq_ut0); cq_ut0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define CQ_UT_DECL unsigned long long cq_ut0 = __builtin_readcyclecounter()
-#else
-#define CQ_UT(slot) do {} while (0)
-#define CQ_UT_DECL do {} while (0)
-#endif
-// the tile in C (load_tile) against the node's image; the updated tile is stored
-// NEXT: the wave has another tile (at column col_next) after this one: it is touched (touch_tile) once this one is in registers.
-// (Tried in round 4 and measured no faster: the next tile's row groups requested in phase C, each right behind the store
-// that frees its registers - with the touches the tile load is not what a wave waits for; without them the last row
-// groups arrive late: 117 against 108 us for 64 tiles x 64 nodes, tools/probes/cq_upd_probe.hip.)
-template <bool TREE, bool NEXT>
-__device__ __forceinline__ void compute_tile(gdbl* Y, long ld, const int (&base)[4], int nrb, int col0, d4 (&C)[16], const ldbl* V, const ldbl* OPS,
-                                             int col_next, unsigned touch_off) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  gdbl* cp = Y + (long)(col0 + c) * ld + 4 * g;
-  // LDS offsets: p even / odd variants absorb the bit-4 part of the swizzle
-  int aE[4], aO[4], cE[4], cO[4];
-  {
-    const int sc = sig(c);
+struct TileAddr {
+  const ldbl* V;                // the node's image
+  unsigned loff;                // this lane's place in a tile: column lane & 15, rows 4 (lane >> 4) (bytes; the segment pointers are uniform,
+                                // so that global loads and stores take them from scalar registers: 16 address registers fewer)
+  const ldbl* ops;              // operand images (uniform: the lane offset is added where phase B starts - kept in a register across the
+                                // phases it was spilled, and a scratch reload waits for every outstanding global load as well)
+};
+// phase A (TR = false): [p & 1][row group >> 3][e]; phase C (TR = true): [p & 1][row group >> 3][s].  Computed at the start of each
+// phase of each tile from two lane constants the optimiser cannot see through (else the sixteen addresses are hoisted out of the
+// tile loop and spilled, or folded into > 16-bit immediates and re-added before every read).
+template <bool TR>
+__device__ __forceinline__ void phase_addr(const ldbl* (&P)[2][2][4], const ldbl* V) {
+  int g = (threadIdx.x & 63) >> 4, sc = sig(threadIdx.x & 15);
+  asm volatile("" : "+v"(g), "+v"(sc));
+  const int zc = swz(sc);
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int m = 4 * g + e, z = swz(m);
-      const int lo = m * 64 + (sc ^ (z & 15)), hi = 16 * (z >> 4);
-      aE[e] = lo + hi; aO[e] = lo - hi;
-    }
-    const int z = swz(sc);
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const int lo = sc * 64 + ((4 * g + s) ^ (z & 15)), hi = 16 * (z >> 4);
-      cE[s] = lo + hi; cO[s] = lo - hi;
-    }
+  for (int e = 0; e < 4; e++) {
+    const int m = 4 * g + e, z = TR ? zc : swz(m);
+    const int lo = TR ? sc * 64 + (m ^ (z & 15)) : m * 64 + (sc ^ (z & 15)), hi = 16 * (z >> 4);
+    P[0][0][e] = V + lo + hi; P[1][0][e] = V + lo - hi; P[0][1][e] = V + lo + hi + 8192; P[1][1][e] = V + lo - hi + 8192;
   }
-#ifdef CQ_NO_LDS
-#ifndef CQ_NCST
-#define CQ_NCST 16
-#endif
-  double cst[CQ_NCST];                 // the stand-in operands: CQ_NCST registers (a power of two), filled once
 #pragma unroll
-  for (int k = 0; k < CQ_NCST; k++) cst[k] = CQ_NO_LDS_VALUE(threadIdx.x * 16 + k);
-#endif
-  CQ_UT_DECL;
-#ifdef CQ_UPROF
-  { double sink = 0; for (int rb = 0; rb < 16; rb++) sink += C[rb][0] + C[rb][3]; if (sink == 1.2345e301) cp[0] = sink; }   // wait for the tile here
-  CQ_UT(1);
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) asm volatile("" : "+v"(P[i][j][k]));
+}
+constexpr int groupA_next(bool tree, int k) {          // phase A walks (p, rb) = (k >> 4, k & 15); the next group not skipped (64: none)
+  for (int q = k + 1; q < 64; q++) if (!tree_skip(tree, q & 15, q >> 4)) return q;
+  return 64;
+}
+__device__ __forceinline__ d4 mfma_negA(double a, double b, d4 c) {          // c - a b  (gfx940+: the f64 MFMA's BLGP field negates A / B / C)
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
+// seg[s]: the tile's column `lane & 15`, rows base[s] + 4 (lane >> 4) of segment s; segn: the same of the wave's next tile (touched)
+template <bool TREE>
+__device__ __forceinline__ void compute_tile(gdbl* const (&seg)[4], int nrb, d4 (&C)[16], const TileAddr& A, int cq_tr_tile = 0, const gdbl* Yt = nullptr, long ldt = 0,
+                                               const int* baset = nullptr, int col_next = 0, unsigned touch_off = 0) {
+  d4 w[4];
+#ifdef CQ_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CQ_TR(1);
 #endif
   // ------------------------------------------------ phase A: W0_p = V_p^T C
-  // The LDS operands are fetched one row group ahead by hand and the schedule is pinned per group: left alone, the
-  // scheduler hoists dozens of ds_reads above the MFMA chain and spills the C tile.
-  d4 w[4];
+  {
+    const ldbl* pa[2][2][4];
+    phase_addr<false>(pa, A.V);
+    double a[2][4];
+    int par = 0;
 #pragma unroll
-  for (int p = 0; p < 4; p++) {
+    for (int e = 0; e < 4; e++) a[0][e] = pa[0][0][e][0];
     d4 acc = d4{0, 0, 0, 0};
-    // two base pointers per operand: the row-group offset (8 KB per group) then fits the 16-bit ds_read immediate;
-    // with one base the compiler materialises an address register per (group, e) - 204 of them, spilled
-    const ldbl* Vlo[4];
-    const ldbl* Vhi[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) { Vlo[e] = V + ((p & 1) ? aO[e] : aE[e]); Vhi[e] = Vlo[e] + 8192; }
-    double a[4], an[4];
-#pragma unroll
-#ifdef CQ_NO_LDS          // probe builds: the reflector operands are constants in registers (no LDS traffic at all)
-    for (int e = 0; e < 4; e++) a[e] = cst[(e + 4 * p) & (CQ_NCST - 1)];
-#else
-    for (int e = 0; e < 4; e++) a[e] = Vlo[e][16 * p];                       // row group 0 is never skipped
-#endif
-#pragma unroll
-    for (int rb = 0; rb < 16; rb++) {
+    for (int k = 0; k < 64; k++) {
+      const int p = k >> 4, rb = k & 15;
       if (tree_skip(TREE, rb, p)) continue;
-      const int nx = tree_next(TREE, rb, p);
-      if (nx < 16) {
+      const int nk = groupA_next(TREE, k), np = nk >> 4, nr = nk & 15;
+      if (rb == 0) acc = d4{0, 0, 0, 0};
 #pragma unroll
-#ifdef CQ_NO_LDS
-        for (int e = 0; e < 4; e++) an[e] = a[e];
-#else
-        for (int e = 0; e < 4; e++) an[e] = (nx < 8) ? Vlo[e][16 * p + 1024 * nx] : Vhi[e][16 * p + 1024 * (nx - 8)];
-#endif
+      for (int e = 0; e < 4; e++) {          // one read of the NEXT group in front of every MFMA of this one
+        if (nk < 64) a[par ^ 1][e] = pa[np & 1][nr >> 3][e][16 * np + 1024 * (nr & 7)];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = mfma(a[par][e], C[rb][e], acc);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int e = 0; e < 4; e++) acc = mfma(a[e], C[rb][e], acc);
-#pragma unroll
-      for (int e = 0; e < 4; e++) a[e] = an[e];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    w[p] = acc;
-    if (NEXT && p == 0) {                       // the tile is in registers by now (the first MFMAs waited for it)
-      touch_tile(Y, ld, base, nrb, col_next, touch_off);
+      if (groupA_next(TREE, k) >= 64 || (groupA_next(TREE, k) >> 4) != p) w[p] = acc;
+      par ^= 1;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  CQ_UT(2);
+  CQ_TR(2);
   // ------------------------------------------------ phase B: W_p = T_p^T (W0_p - sum_{r<p} S_pr W_r)
+  const ldbl* ops = A.ops + (threadIdx.x & 63);
 #pragma unroll
   for (int p = 0; p < 4; p++) {
     d4 t = w[p];
 #pragma unroll
-    for (int r = 0; r < p; r++) {
-      const ldbl* S = OPS + (4 + p * (p - 1) / 2 + r) * 256 + lane;
+    for (int r = 0; r < p; r++)
 #pragma unroll
-      for (int s = 0; s < 4; s++) t = mfma(S[64 * s], w[r][s], t);
-    }
+      for (int s = 0; s < 4; s++) t = mfma(ops[(4 + p * (p - 1) / 2 + r) * 256 + 64 * s], w[r][s], t);
     d4 o = d4{0, 0, 0, 0};
-    const ldbl* T = OPS + p * 256 + lane;
 #pragma unroll
-    for (int s = 0; s < 4; s++) o = mfma(T[64 * s], t[s], o);
+    for (int s = 0; s < 4; s++) o = mfma(ops[p * 256 + 64 * s], t[s], o);
     w[p] = o;
-  }
-#pragma unroll
-  for (int p = 0; p < 4; p++) w[p] = -w[p];
-  CQ_UT(3);
-  // ------------------------------------------------ phase C: C -= sum_p V_p W_p
-  // (the LDS operands of row group rb + 1 are fetched while the MFMAs of row group rb run, as in phase A: fetched right in
-  //  front of their MFMAs, every (row group, sub-panel) waited ~100 cycles for its four reads)
-  double a[4][4], an[4][4];
-  // all sixteen base pointers up front (the image is 128 KB, a ds_read immediate reaches 64 KB: even / odd sub-panel x
-  // lower / upper half) - computed inside the loop they were 256 address adds per tile between the MFMAs
-  const ldbl* cb[2][2][4];
-#pragma unroll
-  for (int s = 0; s < 4; s++) { cb[0][0][s] = V + cE[s]; cb[0][1][s] = V + cE[s] + 8192; cb[1][0][s] = V + cO[s]; cb[1][1][s] = V + cO[s] + 8192; }
-  auto fetch = [&](int rb, double (&dst)[4][4]) {
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      if (tree_skip(TREE, rb, p)) continue;
-#pragma unroll
-#ifdef CQ_NO_LDS
-      for (int s = 0; s < 4; s++) dst[p][s] = cst[(4 * p + s + 5 * rb) & (CQ_NCST - 1)];
-#else
-      for (int s = 0; s < 4; s++) dst[p][s] = cb[p & 1][rb >> 3][s][16 * p + 1024 * (rb & 7)];
-#endif
-    }
-  };
-  fetch(0, a);
-#pragma unroll
-  for (int rb = 0; rb < 16; rb++) {
-    if (rb + 1 < 16) fetch(rb + 1, an);
-    d4 acc = C[rb];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      if (tree_skip(TREE, rb, p)) continue;
-#pragma unroll
-      for (int s = 0; s < 4; s++) acc = mfma(a[p][s], w[p][s], acc);
-    }
-#ifdef CQ_NO_GLOBAL            // probe builds: the tile never leaves the registers (compute-only ceiling of the wave's instruction stream)
-    C[rb] = acc;
-    if (acc[0] == 1.2345e301 && rb < nrb) __builtin_nontemporal_store(acc, reinterpret_cast<gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
-#else
-    if (rb < nrb) __builtin_nontemporal_store(acc, reinterpret_cast<gd4*>(cp + base[rb >> 2] + 16 * (rb & 3)));
-#endif
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-      for (int s = 0; s < 4; s++) a[p][s] = an[p][s];
     __builtin_amdgcn_sched_barrier(0);
   }
-  CQ_UT(4);
+  CQ_TR(3);
+  // the wave's next tile is touched HERE: half a tile (~17 K cycles) before it is loaded.  Touched after the first quarter of
+  // phase A (round 3) a tile waited ~8.8 K cycles for its data, touched here ~3.9 K: a CU's four waves stream 256 KB through
+  // its share of the 4 MB L2 per tile time, and a line touched a whole tile early is gone again when it is wanted.
+  if (col_next > 0) {
+    const int (&bt)[4] = *reinterpret_cast<const int (*)[4]>(baset);
+    touch_tile(Yt, ldt, bt, nrb, col_next, touch_off);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ------------------------------------------------ phase C: C -= sum_p V_p W_p
+  {
+    const ldbl* pc[2][2][4];
+    phase_addr<true>(pc, A.V);
+    double a[2][4];
+    int par = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) a[0][s] = pc[0][0][s][0];
+#pragma unroll
+    for (int rb = 0; rb < 16; rb++) {
+      d4 acc = C[rb];
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        if (tree_skip(TREE, rb, p)) continue;
+        const int nx = pair_next(TREE, rb, p), nr = nx >> 2, np = nx & 3;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if (nx < 64) a[par ^ 1][s] = pc[np & 1][nr >> 3][s][16 * np + 1024 * (nr & 7)];
+          __builtin_amdgcn_sched_barrier(0);
+          acc = mfma_negA(a[par][s], w[p][s], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        par ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#ifdef CQ_NO_GLOBAL
+      C[rb] = acc; if (acc[0] == 1.2345e301) __builtin_nontemporal_store(acc, lane_ptr(seg[rb >> 2], A.loff, 16 * (rb & 3)));
+#else
+      if (rb < nrb) __builtin_nontemporal_store(acc, lane_ptr(seg[rb >> 2], A.loff, 16 * (rb & 3)));
+#endif
+    }
+  }
+  CQ_TR(4);
 }
-
-// ------------------------------------------------------------------------------------------------------------------
-// k_cq_upd: grid (tile groups, nodes of the level, problems), 512 or 256 threads, IMG_DOUBLES doubles of dynamic LDS.
-// Tiles [tfirst + tg * tpg, + tpg) of the columns right of the block, one per wave at a time.
-// (Tried: four-wave workgroups that fetch the next tile while the current one is updated, two tile buffers in the 512
-// registers of a lone wave - the allocator spills 57-206 registers around the two buffers and the kernel is 8 % slower.
-// Round 4, tools/probes/cq_upd_probe.hip, 128 tiles x 64 nodes, all on one box: (i) TWO tiles per wave against the same LDS
-// operands - every ds_read feeds two MFMAs, 256 + 256 registers, no spill - 37-38 against 38-40 TFLOP/s: the LDS operand
-// stream is not what a wave waits for; (ii) the 256 LDS address adds of phase C hoisted (kept): no change - nor is VALU
-// issue; (iii) no global traffic at all (-DCQ_NO_GLOBAL): 44 TFLOP/s = 23 us per tile and wave against 14.7 us of MFMA issue
-// at 2.4 GHz, 20.8 us with half the CUs busy; the shader clock under this load is 2.26 GHz (s_memtime against s_memrealtime,
-// -DCQ_UPROF), so a wave spends ~84 cycles per 64-cycle MFMA whatever stands between them; (iv) the next row group's LDS
-// reads forced right behind the first MFMA of a group (sched_group_barrier; the compiler issues them after the last one, 64
-// cycles before their use): same wait counts as hand analysis (lgkmcnt 6 / 5 / 4), no change; (v) eight-wave workgroups (two
-// waves per SIMD, 256 registers, spills): 30-33 TFLOP/s; (vi) -DCQ_NO_GLOBAL -DCQ_NO_LDS: the same MFMA stream with its A
-// operands in registers - no LDS, no global traffic, no waits.  With SIXTEEN operand registers cycling it reaches 49 (random
-// mantissas) - 52 (1 + k 1e-9) TFLOP/s; with FOUR loop-invariant ones 74 - 76 (the data-sheet peak).  So the ceiling of this
-// stream on this part is set by the variety of the MFMA's source registers (operand fetch from the register file), not by
-// LDS, memory, waits or the clock, and the shipped kernel (40 with memory, 45 without) runs at 80 - 90 % of it.  (By number of
-// distinct A registers: 2 or 4 -> 73.6, 8 -> 63.8, 16 or 32 -> 49.5 TFLOP/s.  Fewer LDS-FED registers do not help: phase C with
-// its operands fetched one sub-panel ahead - 8 instead of 32 registers - 40.2 against 39.5 TFLOP/s.))
-// ------------------------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, int jb, int level, int slot, int node, int tg, int tpg,
-                                         int tfirst, ldbl* lds, unsigned touch_off) {
+                                           int tfirst, ldbl* lds) {
   const int cols16 = (Pr.cols + 15) & ~15;
   if (jb + 64 > Pr.kmax || cols16 <= jb + 64) return;
   const int ntl = (cols16 - jb - 64) >> 4;
@@ -795,56 +788,96 @@ __device__ __forceinline__ void upd_body(const v2::QrProb& Pr, int64_t ws_off, i
   int base[4], cnt[4];
   if (!node_segments(rows32, jb, level, node, base, cnt)) return;
   const int nrb = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) >> 4;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   constexpr int nwave = NT >> 6;
-#ifdef CQ_UPROF
-  const unsigned long long cq_wg_t0 = __builtin_readcyclecounter();
-  const unsigned long long cq_wg_r0 = __builtin_amdgcn_s_memrealtime();
-  struct ClockNote { unsigned long long c0, r0; bool on; __device__ ~ClockNote() { if (on) { atomicAdd(&cq_uprof[5], __builtin_readcyclecounter() - c0); atomicAdd(&cq_uprof[7], __builtin_amdgcn_s_memrealtime() - r0); } } };
-  ClockNote cq_note{cq_wg_t0, cq_wg_r0, threadIdx.x == 0};          // [5] shader-clock cycles, [7] 100 MHz ticks of the workgroup
-#endif
-  // The node's image (148 KB) -> LDS by LDS-DMA: 148 wave-instructions of 1 KiB (global_load_lds_dwordx4, no register
-  // staging), all in flight at once, and the wave's FIRST tile is requested behind them before anybody waits.  (As a plain
-  // copy loop the compiler serialised it - two 16-byte loads, wait, two LDS writes, 18 round trips per thread: ~12 us per
-  // workgroup, as long as two tiles, during which the matrix pipes idle.)
   {
     const gdbl* src = (const gdbl*)Pr.aux + ws_off + (long)slot * IMG_DOUBLES;
-    const int lane = tid & 63;
-    static_assert(IMG_DOUBLES % 128 == 0, "the image is a whole number of 1 KiB pieces");
     for (int ch = wave; ch < IMG_DOUBLES / 128; ch += nwave)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ch * 128 + lane * 2),
                                        (__attribute__((address_space(3))) void*)(lds + ch * 128), 16, 0, 0);
   }
   const int t1 = min(t0 + tpg, ntl);
-  gdbl* Y = (gdbl*)Pr.Y;
-  d4 C[16];
   int t = t0 + wave;
-  if (t < t1) load_tile(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C);
-  __syncthreads();
-#ifdef CQ_UPROF
-  if ((tid & 63) == 0) { atomicAdd(&cq_uprof[0], __builtin_readcyclecounter() - cq_wg_t0); atomicAdd(&cq_uprof[6], 1ull); }
-#endif
-  if (level == 0) {
+  gdbl* seg[4];
+  {
+    gdbl* cp = (gdbl*)Pr.Y + (long)(jb + 64 + 16 * t) * Pr.ld;
+#pragma unroll
+    for (int s = 0; s < 4; s++) seg[s] = cp + base[s];
+  }
+  const long tstep = 16L * nwave * Pr.ld;
+  TileAddr A{lds, 8u * ((unsigned)(lane & 15) * (unsigned)Pr.ld + 4u * (unsigned)(lane >> 4)), lds + IMG_V};
+  auto load = [&](d4 (&C)[16]) {
+    if (nrb == 16) {                    // (a full node: no zero fill - 128 VALU moves per tile otherwise)
+#pragma unroll
+      for (int rb = 0; rb < 16; rb++) C[rb] = __builtin_nontemporal_load(lane_ptr(seg[rb >> 2], A.loff, 16 * (rb & 3)));
+    } else {
+#pragma unroll
+      for (int rb = 0; rb < 16; rb++) {
+        C[rb] = d4{0, 0, 0, 0};
+        if (rb < nrb) C[rb] = __builtin_nontemporal_load(lane_ptr(seg[rb >> 2], A.loff, 16 * (rb & 3)));
+      }
+    }
+  };
+  auto compute = [&](d4 (&C)[16], gdbl* const (&sg)[4], int trt) {
+    const int cnext = NT == 256 && t + nwave < t1 ? jb + 64 + 16 * (t + nwave) : 0;          // (touches only with a lone wave per SIMD)
+    if (level == 0) compute_tile<false>(sg, nrb, C, A, trt, (const gdbl*)Pr.Y, Pr.ld, base, cnext, (unsigned)(IMG_DOUBLES * 8));
+    else compute_tile<true>(sg, nrb, C, A, trt, (const gdbl*)Pr.Y, Pr.ld, base, cnext, (unsigned)(IMG_DOUBLES * 8));
+  };
+  if constexpr (NT == 256) {
+    // One wave per SIMD: static assignment, the wave's next tile touched (touch_tile) while this one is updated.  (Tried: TWO
+    // tile buffers in the 512 registers of a lone wave, the next tile requested as soon as the current one has arrived - 396
+    // registers, no spill, but the compiler waits with vmcnt(0) in front of the first MFMA of every tile, i.e. for the tile
+    // it has just requested as well: no gain.)
+    d4 C[16];
+    if (t < t1) load(C);
+    __syncthreads();
+    int trt = 0;
     for (bool first = true; t < t1; t += nwave, first = false) {
-#ifndef CQ_NO_GLOBAL
-      if (!first) load_tile(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C);
-#endif
-      if (t + nwave < t1) compute_tile<false, true>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C, lds, lds + IMG_V, jb + 64 + 16 * (t + nwave), touch_off);
-      else compute_tile<false, false>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C, lds, lds + IMG_V, 0, touch_off);
+      CQ_TR0(trt);
+      if (!first) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) seg[s] += tstep;
+        load(C);
+      }
+      compute(C, seg, trt++);
     }
   } else {
-    for (bool first = true; t < t1; t += nwave, first = false) {
-      if (!first) load_tile(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C);
-      if (t + nwave < t1) compute_tile<true, true>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C, lds, lds + IMG_V, jb + 64 + 16 * (t + nwave), touch_off);
-      else compute_tile<true, false>(Y, Pr.ld, base, nrb, jb + 64 + 16 * t, C, lds, lds + IMG_V, 0, touch_off);
+    // Two waves per SIMD: the tiles of the group are handed out through a counter in LDS.  (Statically assigned, the second wave
+    // of every SIMD fell behind the first - the older wave wins the issue port - and ran its last tiles alone.)
+    typedef __attribute__((address_space(3))) int lint;
+    lint* ctr = reinterpret_cast<lint*>(lds + IMG_DOUBLES);
+    if (tid == 0) *ctr = nwave;
+    d4 C[16];
+    if (t < t1) load(C);
+    __syncthreads();
+    int trt = 0;
+    gdbl* seg0[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) seg0[s] = seg[s] - 16L * wave * Pr.ld;          // tile t0
+    for (bool first = true; t < t1; first = false) {
+      CQ_TR0(trt);
+      if (!first) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) seg[s] = seg0[s] + 16L * (t - t0) * Pr.ld;
+#ifndef CQ_NO_GLOBAL
+        load(C);
+#endif
+      }
+      compute(C, seg, trt++);
+      int k = 0;
+      if (lane == 0) k = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      t = t0 + __builtin_amdgcn_readfirstlane(k);
     }
   }
 }
 
+// k_cq_upd: grid (tile groups, nodes of the level, problems), IMG_DOUBLES + TOUCH_DOUBLES doubles of dynamic LDS.
+// Tiles [tfirst + tg * tpg, + tpg) of the columns right of the block.  The library launches the 256-thread build (one wave per
+// SIMD); the 512-thread build (two waves per SIMD, tiles handed out through an LDS counter) is kept for tools/probes/cq_upd_probe.hip.
 template <int NT>
 __global__ void __launch_bounds__(NT) k_cq_upd(const v2::QrProb* probs, int64_t ws_off, int jb, int level, int slot0, int tpg, int tfirst) {
   extern __shared__ __attribute__((aligned(16))) double cq_lds_raw[];
-  upd_body<NT>(probs[blockIdx.z], ws_off, jb, level, slot0 + blockIdx.y, blockIdx.y, blockIdx.x, tpg, tfirst, (ldbl*)cq_lds_raw, (unsigned)(IMG_DOUBLES * 8));
+  upd_body<NT>(probs[blockIdx.z], ws_off, jb, level, slot0 + blockIdx.y, blockIdx.y, blockIdx.x, tpg, tfirst, (ldbl*)cq_lds_raw);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -873,7 +906,7 @@ __global__ void __launch_bounds__(256) k_cq_updfac(const v2::QrProb* probs, int 
   }
   b -= nprob * nfac;
   const int tg = b % ntg, node = (b / ntg) % nupd;
-  upd_body<256>(probs[b / (ntg * nupd)], ws_off, jb, level, slot_u + node, node, tg, tpg, 0, lds, (unsigned)(IMG_DOUBLES * 8));
+  upd_body<256>(probs[b / (ntg * nupd)], ws_off, jb, level, slot_u + node, node, tg, tpg, 0, lds);
 }
 
 }  // namespace cq

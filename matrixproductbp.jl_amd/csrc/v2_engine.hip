@@ -105,7 +105,6 @@ static void set_func_attrs_once() {
   if (dev >= 0) { std::lock_guard<std::mutex> lk(g_dev[dev].mu); if (g_dev[dev].attrs) return; g_dev[dev].attrs = true; }
   hipFuncSetAttribute((const void*)v2::k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2::fpanel_lds_bytes(3));
   hipFuncSetAttribute((const void*)cq::k_cq_upd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
-  hipFuncSetAttribute((const void*)cq::k_cq_fac2, hipFuncAttributeMaxDynamicSharedMemorySize, cq::FAC_LDS_DOUBLES * 8);
   hipFuncSetAttribute((const void*)cq::k_cq_updfac, hipFuncAttributeMaxDynamicSharedMemorySize, cq::UPD_LDS_DOUBLES * 8);
   hipFuncSetAttribute((const void*)v2::k_jac_block, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 }
@@ -222,8 +221,8 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       static const double img_us = [] { const char* e = getenv("MPBP_CQ_IMG_US"); return e ? atof(e) : 12.0; }();
       auto tile_groups = [&](int ntl, int n, int& tpg, int& nthr) {
         const int64_t tiles = (int64_t)ntl * n * P;
-        // four-wave workgroups always: the eight-wave build of round 3 (two waves per SIMD at 256 registers, 155 - 495 spills)
-        // measured 30-33 against 38-40 TFLOP/s on every tile-group size (profiles/r04_cq_upd_probe.txt) and was removed
+        // four-wave workgroups always: the fused update + factor launch needs that shape, and the two-waves-per-SIMD build of the
+        // update alone (cq_kernels.h, compute_tile) wins only at >= 128 problems (profiles/r04_cq_upd_probe.txt)
         tpg = 8; nthr = 256;
         if (tiles <= 4 * ncu) { tpg = 4; return; }
         double best = 1e30;
