@@ -678,9 +678,6 @@ constexpr int groupA_next(bool tree, int k) {          // phase A walks (p, rb) 
   for (int q = k + 1; q < 64; q++) if (!tree_skip(tree, q & 15, q >> 4)) return q;
   return 64;
 }
-__device__ __forceinline__ d4 mfma_negA(double a, double b, d4 c) {          // c - a b  (gfx940+: the f64 MFMA's BLGP field negates A / B / C)
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
-}
 // seg[s]: the tile's column `lane & 15`, rows base[s] + 4 (lane >> 4) of segment s; segn: the same of the wave's next tile (touched)
 template <bool TREE>
 __device__ __forceinline__ void compute_tile(gdbl* const (&seg)[4], int nrb, d4 (&C)[16], const TileAddr& A, int cq_tr_tile = 0, const gdbl* Yt = nullptr, long ldt = 0,
@@ -761,7 +758,7 @@ __device__ __forceinline__ void compute_tile(gdbl* const (&seg)[4], int nrb, d4 
         for (int s = 0; s < 4; s++) {
           if (nx < 64) a[par ^ 1][s] = pc[np & 1][nr >> 3][s][16 * np + 1024 * (nr & 7)];
           __builtin_amdgcn_sched_barrier(0);
-          acc = mfma_negA(a[par][s], w[p][s], acc);
+          acc = mfma_na(a[par][s], w[p][s], acc);
           __builtin_amdgcn_sched_barrier(0);
         }
         par ^= 1;

@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(512) k_inblock(const QrProb* probs, AuxLay lay
       if (r < p) {
         const ldbl* S = Sq + (p * (p - 1) / 2 + r) * 256;
 #pragma unroll
-        for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][s], t);
+        for (int s = 0; s < 4; s++) t = mfma_na(S[l15 + 16 * (4 * s + g)], w[r][s], t);
       }
     }
     d4 o = d4{0, 0, 0, 0};
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(512) k_inblock(const QrProb* probs, AuxLay lay
 #pragma unroll
       for (int s2 = 0; s2 < 4; s2++)
 #pragma unroll
-        for (int p = 0; p < NP; p++) a4 = mfma(-w[p][s2], v[p][s2][e], a4);
+        for (int p = 0; p < NP; p++) a4 = mfma_na(w[p][s2], v[p][s2][e], a4);
 #pragma unroll
       for (int r = 0; r < 4; r++) c[r][e] = a4[r];
     }
@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
         if (r < p) {
           const ldbl* S = Sq + (p * (p - 1) / 2 + r) * 256;
 #pragma unroll
-          for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][s], t);
+          for (int s = 0; s < 4; s++) t = mfma_na(S[l15 + 16 * (4 * s + g)], w[r][s], t);
         }
       }
       d4 o = d4{0, 0, 0, 0};
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(256) k_trailU(const QrProb* probs, AuxLay lay,
 #pragma unroll
       for (int s2 = 0; s2 < 4; s2++)
 #pragma unroll
-        for (int p = 0; p < NP; p++) a4 = mfma(-w[p][s2], v[p][s2][e], a4);
+        for (int p = 0; p < NP; p++) a4 = mfma_na(w[p][s2], v[p][s2][e], a4);
 #pragma unroll
       for (int r = 0; r < 4; r++) c[r][e] = a4[r];
     }
@@ -995,7 +995,7 @@ __global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailU_coop(const QrPr
         if (r < p) {
           const ldbl* S = Sq + (p * (p - 1) / 2 + r) * 256;
 #pragma unroll
-          for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
+          for (int s = 0; s < 4; s++) t = mfma_na(S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
         }
       }
       d4 o = d4{0, 0, 0, 0};
@@ -1036,10 +1036,10 @@ __global__ void __launch_bounds__(512, NT == 1 ? 4 : 2) k_trailU_coop(const QrPr
           const d2 v = *reinterpret_cast<const ld2*>(vb + (16 * p + 4 * s2 + g) * QR_VS_LD + 2 * l15);
           if (NT > 1 && nt > 1) {
 #pragma unroll
-            for (int e = 0; e < 2; e++) { acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]); acc[NT - 1][e] = mfma(-w[p][NT - 1][s2], v[e], acc[NT - 1][e]); }
+            for (int e = 0; e < 2; e++) { acc[0][e] = mfma_na(w[p][0][s2], v[e], acc[0][e]); acc[NT - 1][e] = mfma_na(w[p][NT - 1][s2], v[e], acc[NT - 1][e]); }
           } else {
 #pragma unroll
-            for (int e = 0; e < 2; e++) acc[0][e] = mfma(-w[p][0][s2], v[e], acc[0][e]);
+            for (int e = 0; e < 2; e++) acc[0][e] = mfma_na(w[p][0][s2], v[e], acc[0][e]);
           }
         }
 #pragma unroll

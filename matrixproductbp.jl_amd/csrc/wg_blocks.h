@@ -869,7 +869,7 @@ __device__ __forceinline__ void qr_trail(gdbl* Y, long ld, int rows32, int j0, i
         for (int e = 0; e < 2; e++) {
           d4 acc = d4{c[q][0][e], c[q][1][e], c[q][2][e], c[q][3][e]};
 #pragma unroll
-          for (int s2 = 0; s2 < 4; s2++) acc = mfma(-w[q][s2], v[s2][e], acc);
+          for (int s2 = 0; s2 < 4; s2++) acc = mfma_na(w[q][s2], v[s2][e], acc);
 #pragma unroll
           for (int r = 0; r < 4; r++) c[q][r][e] = acc[r];
         }
@@ -943,7 +943,7 @@ __device__ __forceinline__ void qr_trail2(gdbl* Y, long ld, int rows32, int j0, 
     for (int s = 0; s < 4; s++) wa[q] = mfma(TsA[(4 * s + g) + 16 * l15], wa0[q][s], wa[q]);
     d4 t = wb0[q];                          // t = Vb^T C - S Wa
 #pragma unroll
-    for (int s = 0; s < 4; s++) t = mfma(-Sm[l15 + 16 * (4 * s + g)], wa[q][s], t);
+    for (int s = 0; s < 4; s++) t = mfma_na(Sm[l15 + 16 * (4 * s + g)], wa[q][s], t);
     wb[q] = d4{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; s++) wb[q] = mfma(TsB[(4 * s + g) + 16 * l15], t[s], wb[q]);
@@ -983,7 +983,7 @@ __device__ __forceinline__ void qr_trail2(gdbl* Y, long ld, int rows32, int j0, 
         for (int e = 0; e < 2; e++) {
           d4 acc = d4{c[q][0][e], c[q][1][e], c[q][2][e], c[q][3][e]};
 #pragma unroll
-          for (int s2 = 0; s2 < 4; s2++) { acc = mfma(-wa[q][s2], va[s2][e], acc); acc = mfma(-wb[q][s2], vb[s2][e], acc); }
+          for (int s2 = 0; s2 < 4; s2++) { acc = mfma_na(wa[q][s2], va[s2][e], acc); acc = mfma_na(wb[q][s2], vb[s2][e], acc); }
 #pragma unroll
           for (int r = 0; r < 4; r++) c[q][r][e] = acc[r];
         }
@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void qr_tile_update_all(gdbl* Y, long ld, int rows32,
     for (int e = 0; e < 2; e++) {
       d4 a = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
 #pragma unroll
-      for (int s2 = 0; s2 < 4; s2++) a = mfma(-wv[s2], v[s2][e], a);
+      for (int s2 = 0; s2 < 4; s2++) a = mfma_na(wv[s2], v[s2][e], a);
 #pragma unroll
       for (int r = 0; r < 4; r++) c[r][e] = a[r];
     }
@@ -1124,7 +1124,7 @@ __device__ __forceinline__ void qr_tile_update2_all(gdbl* Y, long ld, int rows32
     for (int s = 0; s < 4; s++) wa[q] = mfma(TsA[(4 * s + g) + 16 * l15], wa0[s], wa[q]);
     d4 t = wb0;
 #pragma unroll
-    for (int s = 0; s < 4; s++) t = mfma(-Sm[l15 + 16 * (4 * s + g)], wa[q][s], t);
+    for (int s = 0; s < 4; s++) t = mfma_na(Sm[l15 + 16 * (4 * s + g)], wa[q][s], t);
 #pragma unroll
     for (int s = 0; s < 4; s++) wb[q] = mfma(TsB[(4 * s + g) + 16 * l15], t[s], wb[q]);
   }
@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void qr_tile_update2_all(gdbl* Y, long ld, int rows32
       for (int e = 0; e < 2; e++) {
         d4 acc = d4{c[0][e], c[1][e], c[2][e], c[3][e]};
 #pragma unroll
-        for (int s2 = 0; s2 < 4; s2++) { acc = mfma(-wa[q][s2], va[s2][e], acc); acc = mfma(-wb[q][s2], vb[s2][e], acc); }
+        for (int s2 = 0; s2 < 4; s2++) { acc = mfma_na(wa[q][s2], va[s2][e], acc); acc = mfma_na(wb[q][s2], vb[s2][e], acc); }
 #pragma unroll
         for (int r = 0; r < 4; r++) c[r][e] = acc[r];
       }
@@ -1235,7 +1235,7 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
       for (int r = 0; r < p; r++) {
         const ldbl* S = Sq[p * (p - 1) / 2 + r];
 #pragma unroll
-        for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
+        for (int s = 0; s < 4; s++) t = mfma_na(S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
       }
       d4 o = d4{0, 0, 0, 0};
 #pragma unroll
@@ -1279,7 +1279,7 @@ __device__ __forceinline__ void qr_trail4(gdbl* Y, long ld, int rows32, int j0, 
 #pragma unroll
           for (int s2 = 0; s2 < 4; s2++)
 #pragma unroll
-            for (int p = 0; p < 4; p++) acc = mfma(-w[p][q][s2], v[p][s2][e], acc);
+            for (int p = 0; p < 4; p++) acc = mfma_na(w[p][q][s2], v[p][s2][e], acc);
 #pragma unroll
           for (int r = 0; r < 4; r++) c[q][r][e] = acc[r];
         }
@@ -1344,7 +1344,7 @@ __device__ __attribute__((noinline)) void qr_tile_update4_all(gdbl* Y, long ld, 
     for (int r = 0; r < p; r++) {
       const ldbl* S = Sq[p * (p - 1) / 2 + r];
 #pragma unroll
-      for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][s], t);
+      for (int s = 0; s < 4; s++) t = mfma_na(S[l15 + 16 * (4 * s + g)], w[r][s], t);
     }
     d4 o = d4{0, 0, 0, 0};
 #pragma unroll
@@ -1380,7 +1380,7 @@ __device__ __attribute__((noinline)) void qr_tile_update4_all(gdbl* Y, long ld, 
 #pragma unroll
       for (int s2 = 0; s2 < 4; s2++)
 #pragma unroll
-        for (int p = 0; p < 4; p++) a4 = mfma(-w[p][s2], v[p][s2][e], a4);
+        for (int p = 0; p < 4; p++) a4 = mfma_na(w[p][s2], v[p][s2][e], a4);
 #pragma unroll
       for (int r = 0; r < 4; r++) c[r][e] = a4[r];
     }
@@ -1428,13 +1428,18 @@ __device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, in
   };
   auto stage_store = [&](int m, int h, d4 v) {
     ldbl* dst = Vs + (m & 1) * QR_VM_STAGE + sc * QR_VM_LD + 32 * h + 4 * sr;
+    if (m == 0) {                                                    // only the first 64 rows hold the panels' diagonal blocks
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int rp = 64 * m + 32 * h + 4 * sr + e - 16 * spanel;     // row relative to this panel's diagonal block
-      double a = v[e];
-      a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
-      v[e] = (rp >= 0 && 2 * m + h < nst) ? a : 0.0;                 // rows past the matrix: zero reflector rows
+      for (int e = 0; e < 4; e++) {
+        const int rp = 32 * h + 4 * sr + e - 16 * spanel;            // row relative to this panel's diagonal block
+        double a = v[e];
+        a = (rp < 16) ? ((rp > scol) ? a : ((rp == scol) ? 1.0 : 0.0)) : a;
+        v[e] = (rp >= 0) ? a : 0.0;
+      }
     }
+    // rows past the matrix: zero reflector rows.  A uniform test: inside the stage loops the store is two LDS writes and no
+    // VALU instruction (the per-element masks above were ~40 VALU instructions per half stage beside 64 MFMAs).
+    if (2 * m + h >= nst) v = d4{0, 0, 0, 0};
     *reinterpret_cast<ld2*>(dst) = d2{v[0], v[1]};
     *reinterpret_cast<ld2*>(dst + 2) = d2{v[2], v[3]};
   };
@@ -1510,7 +1515,7 @@ __device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, in
         for (int r = 0; r < p; r++) {
           const ldbl* S = Sq[p * (p - 1) / 2 + r];
 #pragma unroll
-          for (int s = 0; s < 4; s++) t = mfma(-S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
+          for (int s = 0; s < 4; s++) t = mfma_na(S[l15 + 16 * (4 * s + g)], w[r][q][s], t);
         }
         d4 o = d4{0, 0, 0, 0};
 #pragma unroll
@@ -1567,7 +1572,7 @@ __device__ __forceinline__ void qr_trail4_coop_pass(gdbl* Y, long ld, int j0, in
 #pragma unroll
                 for (int e = 0; e < 2; e++)
 #pragma unroll
-                  for (int q = 0; q < NR; q++) acc[q][e] = mfma(-w[p][q][s2], v[e], acc[q][e]);
+                  for (int q = 0; q < NR; q++) acc[q][e] = mfma_na(w[p][q][s2], v[e], acc[q][e]);
               }
 #pragma unroll
             for (int q = 0; q < NR; q++)

@@ -35,6 +35,12 @@ enum { PH_STAGE = 0, PH_Y1, PH_Y2, PH_QR1_PANEL, PH_QR1_TRAIL, PH_LF, PH_N, PH_M
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// c - a b: on gfx940+ the BLGP field of the f64 MFMA negates A / B / C (bit 0: A).  Negating the operand instead is a VALU
+// instruction per use inside the MFMA loops, and on gfx950 every VALU instruction takes its cycles from the fp64 MFMAs of
+// the same SIMD (tools/probes/mfma_operand_probe.hip).
+__device__ __forceinline__ d4 mfma_na(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
 
 // Workgroup barrier that orders LDS traffic only: this wave's LDS operations are complete (lgkmcnt(0)), outstanding
 // global loads stay in flight across it (a __syncthreads() drains vmcnt as well and serialises every prefetch that spans
