@@ -216,9 +216,11 @@ int qr_batch(hipStream_t st, const v2::QrProb* d_probs, const std::vector<QrDims
       static const bool no_fuse = getenv("MPBP_DEBUG_CQ_NOFUSE") != nullptr;
       const int cols16_max = r16i(cols_max);
       // tiles per workgroup: one tile per wave and four-wave workgroups for the small upper levels; else the number of tile
-      // groups with the fewest (rounds over the CUs) x (time of a workgroup: ~12 us of image load + 6.2 us per tile, measured
-      // with the chip full) - it decides how the last round is filled
-      static const double img_us = [] { const char* e = getenv("MPBP_CQ_IMG_US"); return e ? atof(e) : 12.0; }();
+      // groups with the fewest (rounds over the CUs) x (time of a workgroup: a fixed part + 6.2 us per tile, measured with the
+      // chip full) - it decides how the last round is filled.  The fixed part: ~15 us of image load + the first tile's wait;
+      // swept 4 ... 50 us on four shapes (round 4, with the rewritten tile update): flat within 1 % from 8 to 50 on the
+      // many-problem shapes, 6400 x 1600 x 16 22.0 -> 21.4 ms and 16384 x 4096 26.9 -> 26.7 ms at 30
+      static const double img_us = [] { const char* e = getenv("MPBP_CQ_IMG_US"); return e ? atof(e) : 30.0; }();
       auto tile_groups = [&](int ntl, int n, int& tpg, int& nthr) {
         const int64_t tiles = (int64_t)ntl * n * P;
         // four-wave workgroups always: the fused update + factor launch needs that shape, and the two-waves-per-SIMD build of the

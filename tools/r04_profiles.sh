@@ -25,10 +25,14 @@ for shape in 6400x1600x16 16384x4096x1; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 --output-format csv -d $G/r04_pmc_${shape}_MFMA -o p -- python3 tools/qrbench3.py $shape > $G/r04_pmc_${shape}_MFMA.log 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $G/r04_pmc_${shape}_LDS -o p -- python3 tools/qrbench3.py $shape > $G/r04_pmc_${shape}_LDS.log 2>&1 || echo "LDS pmc pass failed"
 done
-# probes of the node factorisation and of the update (tools/probes/cq_fac_probe.hip, cq_upd_probe.hip)
+# probes of the node factorisation, of the fp64 MFMA issue rate and of the update (tools/probes/cq_fac_probe.hip, mfma_operand_probe.hip, cq_upd_probe.hip;
+# the first part of profiles/r04_cq_upd_probe.txt - the round-3 tile code - was taken before that code was removed)
 ( echo "# tools/_cq_fac_new.bin (cq::k_cq_fac2 of the shipped header; -DCQ_PROF build below)"; timeout -k 5 60 tools/_cq_fac_new.bin; timeout -k 5 60 tools/_cq_fac_new_prof.bin
   echo "# tools/_cq_fac_old.bin (the round-3 header: run-time column index)"; timeout -k 5 60 tools/_cq_fac_old.bin ) > $G/r04_cq_fac_probe.txt 2>&1
-( echo "# tools/_cq_upd_probe.bin 128 (cq::k_cq_upd of the shipped header: 128 trailing tiles x 64 nodes)"; timeout -k 5 60 tools/_cq_upd_probe.bin 128
-  echo "# -DCQ_NO_GLOBAL (the tile never leaves the registers)"; timeout -k 5 60 tools/_cq_upd_probe_nog.bin 128
-  echo "# -DCQ_UPROF (per-phase cycle counters and the shader clock; the counters slow the kernel down)"; timeout -k 5 60 tools/_cq_upd_probe_prof.bin 128 ) > $G/r04_cq_upd_probe.txt 2>&1
+( echo "# tools/probes/mfma_operand_probe.hip"; timeout -k 5 60 tools/_mfma_operand.bin ) > $G/r04_mfma_operand_probe.txt 2>&1
+( echo "# tools/_cq_upd_probe256.bin 256 (cq::k_cq_upd<256> of the shipped header: 256 trailing tiles x 64 nodes)"; timeout -k 5 60 tools/_cq_upd_probe256.bin 256
+  echo "# the same, 1024 tiles (four rounds of workgroups at 64 tiles per group)"; timeout -k 5 60 tools/_cq_upd_probe256.bin 1024
+  echo "# -DCQ_TRACE, 256 tiles"; timeout -k 5 60 tools/_cq_upd_probe_tr.bin 256 | cut -c1-330
+  echo "# -DCQ_NT=512 (two waves per SIMD, tiles through an LDS counter), 256 tiles"; timeout -k 5 60 tools/_cq_upd_probe512.bin 256
+  echo "# -DCQ_NT=512, 1024 tiles"; timeout -k 5 60 tools/_cq_upd_probe512.bin 1024 ) > $G/r04_cq_upd_probe_z.txt 2>&1
 ls $G/r04_profK $G/r04_pmc_FETCH_SIZE
