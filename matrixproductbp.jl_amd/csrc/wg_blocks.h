@@ -213,17 +213,24 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
         G.kin |= kin ? (1u << u) : 0u;
       }
     };
-    int tl = tile0 < 0 ? wave : tile0;
-    if (tl < ntile) {
+    // The tile loop with the number of 16-row tiles of this M block a compile-time constant: as a run-time bound every (tile, k-step)
+    // sat in its own exec-masked basic block - address add, ds_read, s_waitcnt lgkmcnt(0), two selects, MFMA: the LDS latency exposed
+    // once per MFMA and 4 VALU instructions beside each (tools/valu_audit.py).  The A operand needs no mask at all: a row of the output
+    // depends on that row of A only, rows >= mrows are never stored, and past the end of K the B operand is zero (A is read from a
+    // clamped, valid address there).
+    auto tiles = [&](auto ntm_c) {
+      constexpr int NTM = decltype(ntm_c)::value;
+      int tl = tile0 < 0 ? wave : tile0;
+      if (tl >= ntile) return;
       int j = tl * 16 + l15;
       bool jin = j < N;
       long cofs = jin ? (long)xco(j) : 0;
       Grp cur, nxt;
       fetch(cofs, 0, cur);
       for (;;) {
-        d4 acc[6];
+        d4 acc[NTM];
 #pragma unroll
-        for (int t = 0; t < 6; t++) acc[t] = d4{0, 0, 0, 0};
+        for (int t = 0; t < NTM; t++) acc[t] = d4{0, 0, 0, 0};
         const int tl2 = tl + tstride;
         const int j2 = tl2 * 16 + l15;
         const bool jin2 = j2 < N;
@@ -236,21 +243,94 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
             const bool kin = (cur.kin >> u) & 1u;
             const double bv = (kin && jin) ? cur.b[u] : 0.0;
 #pragma unroll
-            for (int t = 0; t < 6; t++) {
-              if (t < ntm) {
-                const double av = Sp[s_ro[t] + cur.so[u]];          // always a valid address (clamped maps): load, then mask
-                const double a = (s_in[t] && kin) ? av : 0.0;
-                acc[t] = mfma(a, bv, acc[t]);
-              }
-            }
+            for (int t = 0; t < NTM; t++) acc[t] = mfma(Sp[s_ro[t] + cur.so[u]], bv, acc[t]);
           }
           cur = nxt;
         }
         if (jin) {
           const long oc = (long)oco(j);
 #pragma unroll
-          for (int t = 0; t < 6; t++) {
-            if (t < ntm) {
+          for (int t = 0; t < NTM; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int row = t * 16 + g + 4 * r;
+              if (row < mrows) {
+                OP p = Op + (long)oro(mb + row) + oc;
+                double v = acc[t][r];
+                if (accumulate) v += *p;
+                if (NTO) __builtin_nontemporal_store(v, p); else *p = v;
+              }
+            }
+          }
+        }
+        tl = tl2;
+        if (tl >= ntile) break;
+        j = j2; jin = jin2; cofs = cofs2;
+      }
+    };
+    // K <= 40 (every contraction of configs[1]): the k-dependent parts of the index maps - integer divisions by run-time bond
+    // dimensions, 64-bit products: ~100 VALU instructions per group of five k-steps, re-evaluated for every tile - are evaluated
+    // ONCE per M block and kept in registers; a tile then costs one 64-bit add per X load and one add per A operand.
+    constexpr int NGC = 2;
+    if (nks <= 5 * NGC) {
+      long xr_[NGC][5], so_[NGC][5];
+      unsigned kinm[NGC];
+#pragma unroll
+      for (int gi = 0; gi < NGC; gi++) {
+        kinm[gi] = 0;
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          const int k = 4 * (5 * gi + u) + g;
+          const bool kin = (5 * gi + u < nks) && k < K;
+          const int kc = kin ? k : 0;
+          xr_[gi][u] = (long)xro(kc);
+          so_[gi][u] = (long)sco(kc);
+          kinm[gi] |= kin ? (1u << u) : 0u;
+        }
+      }
+      auto tiles_c = [&](auto ntm_c) {
+        constexpr int NTM = decltype(ntm_c)::value;
+        int tl = tile0 < 0 ? wave : tile0;
+        if (tl >= ntile) return;
+        int j = tl * 16 + l15;
+        bool jin = j < N;
+        long cofs = jin ? (long)xco(j) : 0;
+        double cb[5], nb[5];
+        auto fetchc = [&](long co, int gi, double (&b)[5]) {          // gi: 0 or 1, resolved at compile time after unrolling
+#pragma unroll
+          for (int u = 0; u < 5; u++) {
+            const long o = (gi == 0 ? xr_[0][u] : xr_[NGC - 1][u]) + co;
+            b[u] = NTX ? __builtin_nontemporal_load(Xp + o) : Xp[o];
+          }
+        };
+        fetchc(cofs, 0, cb);
+        for (;;) {
+          d4 acc[NTM];
+#pragma unroll
+          for (int t = 0; t < NTM; t++) acc[t] = d4{0, 0, 0, 0};
+          const int tl2 = tl + tstride;
+          const int j2 = tl2 * 16 + l15;
+          const bool jin2 = j2 < N;
+          long cofs2 = 0;
+#pragma unroll
+          for (int gi = 0; gi < NGC; gi++) {
+            if (5 * gi >= nks) break;                                   // wave-uniform
+            if (gi + 1 < NGC && 5 * (gi + 1) < nks) fetchc(cofs, gi + 1, nb);
+            else if (tl2 < ntile) { cofs2 = jin2 ? (long)xco(j2) : 0; fetchc(cofs2, 0, nb); }
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+              const bool kin = (kinm[gi] >> u) & 1u;
+              const double bv = (kin && jin) ? cb[u] : 0.0;
+#pragma unroll
+              for (int t = 0; t < NTM; t++) acc[t] = mfma(Sp[s_ro[t] + so_[gi][u]], bv, acc[t]);
+            }
+#pragma unroll
+            for (int u = 0; u < 5; u++) cb[u] = nb[u];
+          }
+          if (jin) {
+            const long oc = (long)oco(j);
+#pragma unroll
+            for (int t = 0; t < NTM; t++) {
 #pragma unroll
               for (int r = 0; r < 4; r++) {
                 const int row = t * 16 + g + 4 * r;
@@ -263,11 +343,28 @@ __device__ __attribute__((noinline)) void gemm_direct(int M, int N, int K, SP Sp
               }
             }
           }
+          tl = tl2;
+          if (tl >= ntile) break;
+          j = j2; jin = jin2; cofs = cofs2;
         }
-        tl = tl2;
-        if (tl >= ntile) break;
-        j = j2; jin = jin2; cofs = cofs2;
+      };
+      switch (ntm) {
+        case 1: tiles_c(std::integral_constant<int, 1>{}); break;
+        case 2: tiles_c(std::integral_constant<int, 2>{}); break;
+        case 3: tiles_c(std::integral_constant<int, 3>{}); break;
+        case 4: tiles_c(std::integral_constant<int, 4>{}); break;
+        case 5: tiles_c(std::integral_constant<int, 5>{}); break;
+        default: tiles_c(std::integral_constant<int, 6>{}); break;
       }
+      continue;
+    }
+    switch (ntm) {
+      case 1: tiles(std::integral_constant<int, 1>{}); break;
+      case 2: tiles(std::integral_constant<int, 2>{}); break;
+      case 3: tiles(std::integral_constant<int, 3>{}); break;
+      case 4: tiles(std::integral_constant<int, 4>{}); break;
+      case 5: tiles(std::integral_constant<int, 5>{}); break;
+      default: tiles(std::integral_constant<int, 6>{}); break;
     }
   }
   __syncthreads();
