@@ -167,21 +167,41 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
     const int kmax = min(rowsY, Bm);
     // scale = max |R| over the upper trapezoid; Lf^T = R / scale  (column loops: no integer division)
     const int lane_ = tid & 63, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Four columns per wave and step, their loads issued together (a wave walking one column at a time ran this phase - 1.3 MB read
+    // twice, 1.3 MB written - at a dependent round trip per 64 elements: 4.5 % of a configs[1] sweep).  Indices past a column's end
+    // are clamped instead of branched on: a repeated element does not change a maximum, and the copy selects the VALUE, not the load.
+    constexpr int LFC = 4;
     double mx = 0.0;
-    for (int m = wave_; m < Bm; m += WG_WAVES) {
-      const gdbl* yc = Y + (int64_t)ldY * m;
-      const int kend = min(kmax, m + 1);
-      for (int k = lane_; k < kend; k += 64) mx = fmax(mx, fabs(yc[k]));
+    for (int m0 = LFC * wave_; m0 < Bm; m0 += LFC * WG_WAVES) {
+      const int kcap = min(kmax, m0 + LFC);
+      for (int k = lane_; k < kcap; k += 64) {
+        double v[LFC];
+#pragma unroll
+        for (int c = 0; c < LFC; c++) {
+          const int m = min(m0 + c, Bm - 1);
+          v[c] = Y[(int64_t)ldY * m + min(k, min(kmax, m + 1) - 1)];
+        }
+#pragma unroll
+        for (int c = 0; c < LFC; c++) mx = fmax(mx, fabs(v[c]));
+      }
     }
     mx = wg_max(mx, red);
     const double inv = (mx > 0.0 && isfinite(mx)) ? 1.0 / mx : 1.0;
     gdbl* Lf0 = LfS + (int64_t)t * cfg.lf_stride;                   // Lf^T = R: [kmax x Bm], ld kmax
-    for (int m = wave_; m < Bm; m += WG_WAVES) {
-      const gdbl* yc = Y + (int64_t)ldY * m;
-      gdbl* lc = Lf0 + (int64_t)kmax * m;
-      const int kend = min(kmax, m + 1);        // two branch-free loops: a select on the loaded value would
-      for (int k = lane_; k < kend; k += 64) lc[k] = yc[k] * inv;       // turn the load into a branch
-      for (int k = kend + lane_; k < kmax; k += 64) lc[k] = 0.0;
+    for (int m0 = LFC * wave_; m0 < Bm; m0 += LFC * WG_WAVES) {
+      for (int k = lane_; k < kmax; k += 64) {
+        double v[LFC];
+#pragma unroll
+        for (int c = 0; c < LFC; c++) {
+          const int m = min(m0 + c, Bm - 1);
+          v[c] = Y[(int64_t)ldY * m + min(k, min(kmax, m + 1) - 1)];
+        }
+#pragma unroll
+        for (int c = 0; c < LFC; c++) {
+          const int m = m0 + c;
+          if (m < Bm) Lf0[(int64_t)kmax * m + k] = (k < min(kmax, m + 1)) ? v[c] * inv : 0.0;          // wave-uniform branch
+        }
+      }
     }
     if (tid == 0) rdim[t] = kmax;
     __syncthreads();
