@@ -279,9 +279,12 @@ __device__ void run_problem(const EngProb& P, const EngCfg& cfg, double* slot_, 
       Mt[rr + (int64_t)ldM * c] = 0.0;
     }
     for (int64_t idx = tid; idx < (int64_t)ldM * (Rr16 - Rr); idx += WG_THREADS) Mt[(int64_t)ldM * Rr + idx] = 0.0;
-    gemm(r1, Rr, Bn, Lf1, [=](int i) { return (int64_t)i; }, [=](int kk) { return (int64_t)r1 * kk; },
-         Nt, [=](int kk) { return (int64_t)Rr * kk; }, [=](int j) { return j; }, false,
-         Mt, [=](int i) { return i; }, [=](int j) { return (int64_t)ldM * j; }, false, ldsG);
+    // (operand roles: the Rr <= 96 rows of N_t are the M side - ONE block of row tiles - and the r1 columns of Lf1 the N side, so that
+    //  all eight waves own output tiles: 16 columns each per 128-column chunk.  The other way round - r1 as M, round 1 - 3 - only
+    //  ceil(Rr / 16) = 5 of the 8 waves of configs[1] had a tile, over five M blocks.)
+    gemm(Rr, r1, Bn, Nt, [=](int i) { return (int64_t)i; }, [=](int kk) { return (int64_t)Rr * kk; },
+         Lf1, [=](int kk) { return (int64_t)r1 * kk; }, [=](int j) { return j; }, false,
+         Mt, [=](int i) { return (int64_t)ldM * i; }, [=](int j) { return j; }, false, ldsG);
     PROF(PH_MT);
     qr_r(Mt, ldM, r1, Rr, ldsQ, ldsG, pr, &plast, PH_QR2_PANEL, PH_QR2_TRAIL, cfg.force_generic != 0);
     const int k2 = min(r1, Rr);
