@@ -21,10 +21,11 @@ using namespace wgc;
 
 constexpr int GM_MB = 96;    // rows per M block (6 MFMA row tiles)
 constexpr int GM_NT = 128;   // columns per N chunk (one 16-col tile per wave)
-constexpr int GM_KC = 16;    // K per LDS chunk
+constexpr int GM_KC = 32;    // K per LDS chunk: 8 k-steps between two barriers, 8 + 8 loads per thread in flight (16 until round 4: the M_t
+                             // product of configs[1] waited for its loads at every chunk; 8192 doubles of LDS, inside the engine's QR_BIG_DOUBLES)
 constexpr int GM_LDA = 112;  // LDS leading dims: == 16 (mod 32) doubles so that the two 16-lane runs of a
 constexpr int GM_LDB = 144;  // ds_read_b64 half-wave land on disjoint banks
-constexpr int GM_LDS_DOUBLES = GM_KC * (GM_LDA + GM_LDB);   // 4096 doubles = 32 KiB
+constexpr int GM_LDS_DOUBLES = GM_KC * (GM_LDA + GM_LDB);   // 8192 doubles = 64 KiB
 
 template <bool NTX = false, bool NTO = false, class SP, class XP, class OP, class SRO, class SCO, class XRO, class XCO,
           class ORO, class OCO>
@@ -60,12 +61,14 @@ __device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* 
     for (int n0 = 0; n0 < N; n0 += GM_NT) {
       const int ncols = min(GM_NT, N - n0);
       // staging map for X
-      long x_co[4];
-      bool x_in[4];
-      if (xkfast) {      // kk = tid & 15, j = (tid >> 4) + 32e
+      constexpr int NE = GM_KC / 4;          // elements per thread and chunk of each operand (512 threads, 128 x GM_KC tile)
+      constexpr int JS = 512 / GM_KC;        // xkfast: kk = tid % GM_KC, j = tid / GM_KC + JS e
+      long x_co[NE];
+      bool x_in[NE];
+      if (xkfast) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          int j = (tid >> 4) + 32 * e;
+        for (int e = 0; e < NE; e++) {
+          int j = tid / GM_KC + JS * e;
           x_in[e] = j < ncols;
           x_co[e] = x_in[e] ? (long)xco(n0 + j) : 0;
         }
@@ -80,27 +83,27 @@ __device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* 
       const bool w_act = wave * 16 < ncols;
       // Register double buffering: the global loads of chunk k0 + GM_KC are issued before the MFMAs of chunk k0
       // and only written to LDS after them (branch-free clamped loads + selects, so that they stay in flight).
-      double sv[4], xv[4];
+      double sv[NE], xv[NE];
       auto load_chunk = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < NE; e++) {
           const int kk = (tid >> 7) + 4 * e;
           const bool ok = s_in && k0 + kk < K;
           const double v = Sp[s_ro + (long)sco(ok ? k0 + kk : 0)];
           sv[e] = ok ? v : 0.0;
         }
         if (xkfast) {
-          const int kk = tid & 15;
+          const int kk = tid % GM_KC;
           const bool kin = k0 + kk < K;
           const long r = (long)xro(kin ? k0 + kk : 0);
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
+          for (int e = 0; e < NE; e++) {
             const double v = Xp[r + x_co[e]];
             xv[e] = (kin && x_in[e]) ? v : 0.0;
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
+          for (int e = 0; e < NE; e++) {
             const int kk = (tid >> 7) + 4 * e;
             const bool ok = x_in[0] && k0 + kk < K;
             const double v = Xp[(long)xro(ok ? k0 + kk : 0) + x_co[0]];
@@ -113,14 +116,14 @@ __device__ __attribute__((noinline)) void gemm(int M, int N, int K, const gdbl* 
         // ---- stage the S tile As[kk][i] and the X tile Bs[kk][j] from the registers
         if (s_act) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) As[((tid >> 7) + 4 * e) * GM_LDA + si] = sv[e];
+          for (int e = 0; e < NE; e++) As[((tid >> 7) + 4 * e) * GM_LDA + si] = sv[e];
         }
         if (xkfast) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) Bs[(tid & 15) * GM_LDB + (tid >> 4) + 32 * e] = xv[e];
+          for (int e = 0; e < NE; e++) Bs[(tid % GM_KC) * GM_LDB + tid / GM_KC + JS * e] = xv[e];
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; e++) Bs[((tid >> 7) + 4 * e) * GM_LDB + (tid & 127)] = xv[e];
+          for (int e = 0; e < NE; e++) Bs[((tid >> 7) + 4 * e) * GM_LDB + (tid & 127)] = xv[e];
         }
         __syncthreads();
         if (k0 + GM_KC < K) load_chunk(k0 + GM_KC);
